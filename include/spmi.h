@@ -1,0 +1,189 @@
+/*
+ * spmi.h -- C-ABI of libspmi, the MI355X (gfx950) implementation of the
+ * per-snapshot GCN message-passing path of spiro.dtdg.
+ *
+ * The reference (mcgill-cpslab/spiral, package `spiro`) has no FFI of its own:
+ * on this path it calls DGL 0.8.0.post1 (poetry.lock:206-207), whose C++ does
+ * the arithmetic.  Each entry point below names the reference call site whose
+ * work it replaces.
+ *
+ * Conventions
+ *   - every pointer marked "device" is caller-owned device memory on the
+ *     current HIP device; the library never allocates, frees or synchronises
+ *     in a launch entry point (all work is queued on `stream`);
+ *   - workspaces are caller-provided, sized by the matching *_workspace_bytes;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value: 0 = queued successfully, negative = SPMI_ERR_* and
+ *     spmi_last_error() describes the failure (thread-local string);
+ *   - node ids at the boundary are int64 like the reference's ID_TYPE
+ *     (spiro/dtdg/types.py:39); on-device CSR arrays are int32, which bounds
+ *     one snapshot to N < 2^31 nodes and E < 2^31 edges (checked);
+ *   - features are float32 like the reference's FEATURE_TYPE
+ *     (spiro/dtdg/types.py:40), row-major with an explicit leading dimension.
+ */
+#ifndef SPMI_H
+#define SPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMI_OK 0
+#define SPMI_ERR_INVALID_ARG (-1) /* null pointer, negative size, bad enum  */
+#define SPMI_ERR_HIP (-2)         /* a HIP runtime call failed               */
+#define SPMI_ERR_WORKSPACE (-3)   /* workspace too small                      */
+#define SPMI_ERR_RANGE (-4)       /* a node id outside [0, N)                 */
+#define SPMI_ERR_UNSUPPORTED (-5) /* size beyond the int32 on-device limits   */
+
+/* activation codes of the fused epilogues */
+#define SPMI_ACT_NONE 0
+#define SPMI_ACT_RELU 1
+#define SPMI_ACT_LEAKY_RELU 2 /* slope given separately (torch default 0.01) */
+
+/* degree -> norm modes (DGL GraphConv `norm`) */
+#define SPMI_NORM_RSQRT 0 /* clamp(deg,1)^-0.5 : norm='both'            */
+#define SPMI_NORM_RECIP 1 /* 1/clamp(deg,1)    : norm='right' / 'left'  */
+
+int spmi_version(void);
+const char* spmi_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Degrees.  Replaces DGLGraph.in_degrees() (spiro/dtdg/types.py:241) and the
+ * in_degrees()/out_degrees() calls inside dgl GraphConv.forward reached from
+ * staticGraphEncoder.py:113,116.  deg[v] = number of occurrences of v in
+ * ids[0..E); multi-edges count every time.  No atomics: keys-only radix sort
+ * followed by run boundaries, so the result is exact and reproducible.
+ * `status` (device, 1 x int32, caller-zeroed) is set non-zero when an id is
+ * outside [0,N); the offending id is clamped so no access leaves the buffers.
+ * ---------------------------------------------------------------------- */
+size_t spmi_degree_workspace_bytes(int64_t E, int64_t N);
+int spmi_degree(const int64_t* ids /*device [E]*/, int64_t E, int64_t N,
+                int64_t* deg /*device [N]*/, void* ws, size_t ws_bytes,
+                int32_t* status /*device [1]*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * COO -> CSR.  Replaces dgl.graph((src,dst), num_nodes) + DGL's lazy
+ * COOToCSR, reached from spiro/dtdg/types.py:191.  Rows are grouped by
+ * `key` (pass dst for the by-destination CSR used by the forward, src for
+ * the by-source CSR used by the backward); inside a row the entries keep the
+ * original edge order (stable), `indices[j]` is the other endpoint and
+ * `eid[j]` the original edge position.  indptr has N+1 entries.
+ * Implemented as a stable LSB radix sort (<= 8-bit digits) + run boundaries.
+ * ---------------------------------------------------------------------- */
+size_t spmi_coo_to_csr_workspace_bytes(int64_t E, int64_t N);
+int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*device [E]*/,
+                    int64_t E, int64_t N /*key range*/, int64_t N_other /*other range*/,
+                    int32_t* indptr /*device [N+1]*/, int32_t* indices /*device [E]*/,
+                    int32_t* eid /*device [E]*/, void* ws, size_t ws_bytes,
+                    int32_t* status /*device [1]*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Degree -> normaliser.  Replaces `degs.float().clamp(min=1)` followed by
+ * `torch.pow(degs, -0.5)` (norm='both') or `1.0/degs` (norm='right'/'left')
+ * inside dgl GraphConv.forward (call sites staticGraphEncoder.py:113,116).
+ * deg is read from a CSR indptr: deg[v] = indptr[v+1]-indptr[v].
+ * ---------------------------------------------------------------------- */
+int spmi_norm_from_indptr(const int32_t* indptr /*device [N+1]*/, int64_t N, int mode,
+                          float* norm /*device [N]*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Load-balance plan for the aggregation: rows whose degree exceeds
+ * `heavy_thresh` are listed and cut into chunks of `chunk` nonzeros that
+ * separate workgroups sum; the row-per-wavefront kernel skips them.
+ * heavy_rows / heavy_chunk_ptr need capacity E/heavy_thresh + 2 entries.
+ * counts[0] = number of heavy rows, counts[1] = number of chunks (device;
+ * the host reads them back once per snapshot to size the partial buffer).
+ * No counterpart in the reference: DGL's CPU SpMM is row-parallel OpenMP.
+ * ---------------------------------------------------------------------- */
+int spmi_spmm_plan(const int32_t* indptr /*device [N+1]*/, int64_t N, int32_t heavy_thresh,
+                   int32_t chunk, int32_t* heavy_rows, int32_t* heavy_chunk_ptr,
+                   int64_t capacity, int32_t* counts /*device [2]*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused normalised aggregation.  Replaces, in one kernel, the
+ * `feat * norm` source scaling, `graph.update_all(copy_u|u_mul_e, sum)`
+ * (DGL SpMMCsr), the destination scaling, `+ bias` and the activation of
+ * dgl GraphConv.forward (call sites staticGraphEncoder.py:113,116):
+ *
+ *   Y[r,:] = act( dst_scale[r] * sum_{j in row r} w_j * X[indices[j],:] + bias )
+ *   w_j    = (edge_w ? edge_w[j] : 1) * (src_scale ? src_scale[indices[j]] : 1)
+ *
+ * The CSR has n_rows rows (this rank's destination block) and its indices
+ * address rows of X in [0, n_src).  Sums run in CSR order inside a row for
+ * rows up to heavy_thresh; heavier rows are summed chunk-wise in a fixed
+ * order, so results are bit-reproducible run to run (no atomics).
+ * The same entry point computes the backward aggregation when given the
+ * by-source CSR with the two scale vectors exchanged.
+ * n_heavy == 0 disables the heavy path (partial_ws may then be NULL).
+ * ---------------------------------------------------------------------- */
+int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                  int64_t E, const float* X, int64_t ldx, int64_t F,
+                  const float* src_scale /*nullable [n_src]*/,
+                  const float* edge_w /*nullable [E], CSR order*/,
+                  const float* dst_scale /*nullable [n_rows]*/,
+                  const float* bias /*nullable [F]*/, int act, float slope,
+                  float* Y, int64_t ldy,
+                  const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr,
+                  int32_t n_heavy, int32_t n_chunks, int32_t heavy_thresh, int32_t chunk,
+                  float* partial_ws /*device [n_chunks*F]*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Backward of the fused epilogue: gP = gY * act'(Y) and gb = column sums.
+ * Replaces the autograd of `rst + bias` / activation in GraphConv.forward.
+ * gb (nullable) must be zeroed by the caller; it is accumulated by one
+ * atomic per workgroup column, so it is reproducible only to fp32 rounding.
+ * ---------------------------------------------------------------------- */
+int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld,
+                      int act, float slope, float* gP /*[M,F] ld=F*/, float* gb /*nullable [F]*/,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
+ * Recurrent cells, sequence length 1, batch = nodes.  Replace the pointwise
+ * half of torch.nn.GRU / LSTM / RNN as called by SequentialDecoder.forward
+ * and LSTM.forward (implicitTimeModels.py:144-158, 214-230), fused with the
+ * NodeMemory gather `memory[:, ids, :]` (:52-54) and the detached write-back
+ * `memory[:, ids, :] = h` (:48-50, :155-156).  The gate GEMMs
+ * gi = x W_ih^T and gh = h W_hh^T are plain library GEMMs done by the caller.
+ *
+ * Gate order follows torch: GRU r,z,n ; LSTM i,f,g,o.
+ *   h_mem / c_mem : one layer of the node memory, [n_mem_rows, H]
+ *   ids           : nullable; row m of the batch uses memory row ids[m]
+ *                   (NULL = identity, the full-snapshot case)
+ *   h_out         : [M,H] new hidden state (input of the next layer / MLP)
+ *   mem_write     : non-zero -> also store the new state into the memory rows
+ *   saved         : nullable; when given, what the backward needs is stored
+ *                   (GRU [M,5H]: r,z,n,hn,h_old ; LSTM [M,6H]: i,f,g,o,c_old,
+ *                   tanh(c_new) ; RNN: nothing beyond h_out)
+ * The *_prep entry points gather h_old rows into a dense [M,H] matrix for the
+ * caller's h W_hh^T GEMM when ids is not the identity.
+ * ---------------------------------------------------------------------- */
+int spmi_gather_rows(const float* table, int64_t ld, const int64_t* ids, int64_t M, int64_t H,
+                     float* out /*[M,H]*/, void* stream);
+int spmi_gru_gate_fwd(const float* gi /*[M,3H]*/, const float* gh /*[M,3H]*/,
+                      const float* b_ih /*nullable [3H]*/, const float* b_hh /*nullable [3H]*/,
+                      float* h_mem, const int64_t* ids, int64_t M, int64_t H,
+                      float* h_out, int mem_write, float* saved, void* stream);
+int spmi_gru_gate_bwd(const float* gh_out /*[M,H] grad of h_out*/, const float* saved /*[M,5H]*/,
+                      int64_t M, int64_t H, float* g_gi /*[M,3H]*/, float* g_gh /*[M,3H]*/,
+                      float* g_h /*nullable [M,H]: direct path gh_out*z*/, void* stream);
+int spmi_lstm_gate_fwd(const float* gi /*[M,4H]*/, const float* gh /*[M,4H]*/,
+                       const float* b_ih, const float* b_hh, float* h_mem, float* c_mem,
+                       const int64_t* ids, int64_t M, int64_t H, float* h_out, float* c_out,
+                       int mem_write, float* saved, void* stream);
+int spmi_lstm_gate_bwd(const float* gh_out /*[M,H]*/, const float* gc_out /*nullable [M,H]*/,
+                       const float* saved /*[M,6H]*/, int64_t M, int64_t H,
+                       float* g_gates /*[M,4H] = grad of gi and of gh*/,
+                       float* g_c /*nullable [M,H]: grad of c_old*/, void* stream);
+int spmi_rnn_gate_fwd(const float* gi /*[M,H]*/, const float* gh /*[M,H]*/, const float* b_ih,
+                      const float* b_hh, float* h_mem, const int64_t* ids, int64_t M, int64_t H,
+                      float* h_out, int mem_write, void* stream);
+int spmi_rnn_gate_bwd(const float* gh_out /*[M,H]*/, const float* h_out /*[M,H]*/, int64_t M,
+                      int64_t H, float* g_gates /*[M,H]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMI_H */

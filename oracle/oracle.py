@@ -1,0 +1,368 @@
+"""CPU oracle for the spiro.dtdg per-snapshot GCN message-passing path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by spiral_amd/.
+
+Two layers:
+
+* thin ctypes wrappers over oracle/_build/liboracle.so (spmi_oracle.c), the C
+  restatement used for the bit-exact integer checks and as the timed CPU baseline;
+* numpy / torch restatements of the layers above it, each citing the reference
+  lines it follows.  The arithmetic of GraphConv lives in DGL 0.8.0.post1
+  (reference poetry.lock:206-207), which is not vendored; `graphconv_forward`
+  follows DGL's published GraphConv.forward step by step.
+
+Pinning status
+  degree / CSR / citation feature / anchors: pinned by the reference's own
+    fixtures (tests/dtdg/test_types_torch.py:12-14,36-56; tests/core/test_utils.py:47-53).
+  GRU / LSTM / RNN / MLP: pinned by goldens generated from the reference's own torch
+    decoders (tests/golden/make_golden.py).
+  GraphConv aggregation, losses, gradients: PARITY UNPINNED by the reference (it holds
+    no numeric fixture and DGL is absent); guarded by three independent restatements
+    that must agree (C sequential, numpy add.at, scipy CSR).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile spmi_oracle.c with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
+        os.path.join(_HERE, "spmi_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_max_threads.restype = ctypes.c_int
+        _lib.orc_degree.restype = ctypes.c_int
+        _lib.orc_coo_to_csr.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+# ----------------------------------------------------------------------------- integer path
+def degree(ids: np.ndarray, n: int) -> np.ndarray:
+    """DGLGraph.in_degrees()/out_degrees() (spiro/dtdg/types.py:241)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    out = np.zeros(n, dtype=np.int64)
+    rc = lib().orc_degree(_p(ids), ctypes.c_int64(ids.size), ctypes.c_int64(n), _p(out))
+    if rc != 0:
+        raise ValueError("node id out of range")
+    return out
+
+
+def coo_to_csr(key: np.ndarray, other: np.ndarray, n: int, n_other: Optional[int] = None
+               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """dgl.graph((src,dst)) + COOToCSR (spiro/dtdg/types.py:191): stable grouping by key."""
+    key = np.ascontiguousarray(key, dtype=np.int64)
+    other = np.ascontiguousarray(other, dtype=np.int64)
+    n_other = n if n_other is None else n_other
+    e = key.size
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    indices = np.zeros(e, dtype=np.int32)
+    eid = np.zeros(e, dtype=np.int32)
+    rc = lib().orc_coo_to_csr(_p(key), _p(other), ctypes.c_int64(e), ctypes.c_int64(n),
+                              ctypes.c_int64(n_other), _p(indptr), _p(indices), _p(eid))
+    if rc != 0:
+        raise ValueError("node id out of range" if rc == -1 else "out of memory")
+    return indptr, indices, eid
+
+
+def norm_from_indptr(indptr: np.ndarray, mode: str = "rsqrt") -> np.ndarray:
+    """degs.float().clamp(min=1) ** -0.5 (norm='both') or 1/degs (DGL GraphConv.forward)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    n = indptr.size - 1
+    out = np.zeros(n, dtype=np.float32)
+    lib().orc_norm(_p(indptr), ctypes.c_int64(n), ctypes.c_int(0 if mode == "rsqrt" else 1), _p(out))
+    return out
+
+
+_ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
+
+
+def aggregate(indptr, indices, x, src_scale=None, edge_w=None, dst_scale=None, bias=None,
+              act=None, slope: float = 0.01, threads: int = 0) -> np.ndarray:
+    """Sequential CSR-order fp32 aggregation with the GraphConv pre/post scaling (C)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n_rows = indptr.size - 1
+    f = x.shape[1]
+    y = np.empty((n_rows, f), dtype=np.float32)
+
+    def c(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+    ss, ew, ds, b = c(src_scale), c(edge_w), c(dst_scale), c(bias)
+    lib().orc_aggregate(_p(indptr), _p(indices), ctypes.c_int64(n_rows), _p(x), ctypes.c_int64(f),
+                        ctypes.c_int64(f), _p(ss), _p(ew), _p(ds), _p(b), ctypes.c_int(_ACT[act]),
+                        ctypes.c_float(slope), _p(y), ctypes.c_int64(f), ctypes.c_int(threads))
+    return y
+
+
+def aggregate_add_at(src, dst, n_dst, x, w=None) -> np.ndarray:
+    """Independent restatement #2: scatter-add over the COO list (np.add.at)."""
+    msg = x[np.asarray(src)]
+    if w is not None:
+        msg = msg * np.asarray(w, dtype=np.float32)[:, None]
+    out = np.zeros((n_dst, x.shape[1]), dtype=np.float32)
+    np.add.at(out, np.asarray(dst), msg)
+    return out
+
+
+def aggregate_scipy(src, dst, n_dst, n_src, x, w=None) -> np.ndarray:
+    """Independent restatement #3: scipy CSR (duplicates summed) times dense."""
+    import scipy.sparse as sp
+
+    vals = np.ones(len(src), dtype=np.float32) if w is None else np.asarray(w, dtype=np.float32)
+    a = sp.coo_matrix((vals, (np.asarray(dst), np.asarray(src))), shape=(n_dst, n_src)).tocsr()
+    return np.asarray(a @ x, dtype=np.float32)
+
+
+def _activation(y: np.ndarray, act, slope=0.01) -> np.ndarray:
+    if act in (None, "none"):
+        return y
+    if act == "relu":
+        return np.where(y > 0, y, np.float32(0)).astype(np.float32)
+    if act == "leaky_relu":
+        return np.where(y > 0, y, y * np.float32(slope)).astype(np.float32)
+    raise ValueError(act)
+
+
+def graphconv_forward(src, dst, n, x, weight=None, bias=None, norm="both", act=None,
+                      slope: float = 0.01, allow_zero_in_degree: bool = False, edge_weight=None
+                      ) -> np.ndarray:
+    """DGL 0.8 GraphConv.forward, step by step, on CPU in fp32.
+
+    Called by the reference at staticGraphEncoder.py:113,116.  Order of operations:
+    zero-in-degree check; source scaling by out-degree norm ('left','both'); X W first
+    iff in_feats > out_feats; sum aggregation (multi-edges counted, CSR order);
+    destination scaling by in-degree norm ('right','both'); + bias; activation.
+    """
+    if norm not in ("none", "both", "right", "left"):
+        raise ValueError(f"Invalid norm value {norm}")
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    x = np.asarray(x, dtype=np.float32)
+    in_deg = degree(dst, n)
+    if not allow_zero_in_degree and (in_deg == 0).any():
+        raise ValueError("There are 0-in-degree nodes in the graph")
+    indptr, indices, eid = coo_to_csr(dst, src, n, n)
+    ew = None if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)[eid]
+    feat = x
+    if norm in ("left", "both"):
+        degs = np.maximum(degree(src, n).astype(np.float32), np.float32(1))
+        nrm = (degs ** np.float32(-0.5)) if norm == "both" else (np.float32(1) / degs)
+        feat = (feat * nrm[:, None]).astype(np.float32)
+    in_feats = x.shape[1]
+    out_feats = in_feats if weight is None else weight.shape[1]
+    if in_feats > out_feats and weight is not None:
+        feat = (feat @ weight).astype(np.float32)
+        rst = aggregate(indptr, indices, feat, edge_w=ew)
+    else:
+        rst = aggregate(indptr, indices, feat, edge_w=ew)
+        if weight is not None:
+            rst = (rst @ weight).astype(np.float32)
+    if norm in ("right", "both"):
+        degs = np.maximum(in_deg.astype(np.float32), np.float32(1))
+        nrm = (degs ** np.float32(-0.5)) if norm == "both" else (np.float32(1) / degs)
+        rst = (rst * nrm[:, None]).astype(np.float32)
+    if bias is not None:
+        rst = (rst + np.asarray(bias, dtype=np.float32)).astype(np.float32)
+    return _activation(rst, act, slope)
+
+
+def graphconv_torch(src, dst, n, x, weight, bias, norm="both", act=None, slope=0.01,
+                    edge_weight=None):
+    """The same layer in differentiable torch ops (index_add_), for gradient parity.
+
+    x / weight / bias / edge_weight are torch tensors (requires_grad as wanted)."""
+    import torch
+
+    src_t = torch.as_tensor(np.asarray(src), dtype=torch.long)
+    dst_t = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+    feat = x
+    if norm in ("left", "both"):
+        degs = torch.bincount(src_t, minlength=n).float().clamp(min=1)
+        nrm = degs.pow(-0.5) if norm == "both" else 1.0 / degs
+        feat = feat * nrm[:, None]
+
+    def agg(f):
+        msg = f[src_t]
+        if edge_weight is not None:
+            msg = msg * edge_weight[:, None]
+        return torch.zeros(n, f.shape[1], dtype=f.dtype).index_add_(0, dst_t, msg)
+
+    if weight is not None and x.shape[1] > weight.shape[1]:
+        rst = agg(feat @ weight)
+    else:
+        rst = agg(feat)
+        if weight is not None:
+            rst = rst @ weight
+    if norm in ("right", "both"):
+        degs = torch.bincount(dst_t, minlength=n).float().clamp(min=1)
+        nrm = degs.pow(-0.5) if norm == "both" else 1.0 / degs
+        rst = rst * nrm[:, None]
+    if bias is not None:
+        rst = rst + bias
+    if act == "relu":
+        rst = torch.relu(rst)
+    elif act == "leaky_relu":
+        rst = torch.nn.functional.leaky_relu(rst, slope)
+    return rst
+
+
+# ----------------------------------------------------------------------------- container
+def is_sorted(a: np.ndarray) -> bool:
+    """spiro/core/utils.py:24-33."""
+    a = np.asarray(a)
+    return bool(np.all(a[:-1] <= a[1:]))
+
+
+def get_anchor_position(arr: np.ndarray, anchors) -> np.ndarray:
+    """spiro/core/utils.py:36-55: last position (1-based) of each anchor in a sorted array."""
+    pos = np.searchsorted(arr, anchors)[1:]
+    return np.hstack((pos, [arr.shape[0]]))
+
+
+def dispatch(edges: np.ndarray, nodes: np.ndarray, n_timestamps: int, t: int):
+    """VEInvariantDTDG.dispatcher (spiro/dtdg/types.py:183-198): cumulative prefix of the
+    time-sorted tables.  Returns (src, dst, num_nodes, node_feat or None, edge_feat or None)."""
+    na = get_anchor_position(nodes[:, 0], range(n_timestamps))
+    ea = get_anchor_position(edges[:, 0], range(n_timestamps))
+    e = edges[: ea[t]]
+    v = nodes[: na[t]]
+    src = e[:, 1].astype(np.int64)
+    dst = e[:, 2].astype(np.int64)
+    nf = v[:, 1:].astype(np.float32) if v.shape[1] > 1 else None
+    ef = e[:, 3:].astype(np.float32) if e.shape[1] > 3 else None
+    return src, dst, v.shape[0], nf, ef
+
+
+def citation_dispatch(edges: np.ndarray, nodes: np.ndarray, n_timestamps: int, t: int):
+    """CitationGraph.dispatcher (spiro/dtdg/types.py:230-248), including its quirk: the
+    feature matrix that already lost its time column is sliced by node_dimension again
+    (:244-245), so the first real feature is dropped and the last column is the in-degree
+    of snapshot t-1, zero-padded for nodes that did not exist yet."""
+    src, dst, n, nf, ef = dispatch(edges, nodes, n_timestamps, t)
+    citation = np.zeros((n, 1))
+    if t > 0:
+        _, pdst, pn, _, _ = dispatch(edges, nodes, n_timestamps, t - 1)
+        citation[:pn, 0] = degree(pdst, pn)
+    this_nodes = np.hstack((nf.astype(np.float64), citation))
+    feat = this_nodes[:, 1:].astype(np.float32)
+    return src, dst, n, feat, ef
+
+
+# ----------------------------------------------------------------------------- recurrent cells
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRU one step (gate order r,z,n), as run by SequentialDecoder.forward
+    (implicitTimeModels.py:154) with seq_len 1."""
+    hd = h.shape[1]
+    gi = x @ w_ih.T + (0 if b_ih is None else b_ih)
+    gh = h @ w_hh.T + (0 if b_hh is None else b_hh)
+    r = _sigmoid(gi[:, :hd] + gh[:, :hd])
+    z = _sigmoid(gi[:, hd:2 * hd] + gh[:, hd:2 * hd])
+    n = np.tanh(gi[:, 2 * hd:] + r * gh[:, 2 * hd:]).astype(np.float32)
+    return ((1 - z) * n + z * h).astype(np.float32)
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTM one step (gate order i,f,g,o), LSTM.forward (implicitTimeModels.py:225)."""
+    hd = h.shape[1]
+    g = x @ w_ih.T + h @ w_hh.T + (0 if b_ih is None else b_ih) + (0 if b_hh is None else b_hh)
+    i = _sigmoid(g[:, :hd])
+    f = _sigmoid(g[:, hd:2 * hd])
+    gg = np.tanh(g[:, 2 * hd:3 * hd]).astype(np.float32)
+    o = _sigmoid(g[:, 3 * hd:])
+    c2 = (f * c + i * gg).astype(np.float32)
+    return (o * np.tanh(c2)).astype(np.float32), c2
+
+
+def rnn_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.RNN(tanh) one step (implicitTimeModels.py:284-286)."""
+    return np.tanh(x @ w_ih.T + h @ w_hh.T + (0 if b_ih is None else b_ih)
+                   + (0 if b_hh is None else b_hh)).astype(np.float32)
+
+
+def recurrent_step(kind: str, x, h0, params, c0=None):
+    """Stack of n_layers cells with seq_len 1: input of layer k is h' of layer k-1.
+    params[k] = (w_ih, w_hh, b_ih, b_hh).  Returns (out, h_new[L,M,H][, c_new])."""
+    hs, cs = [], []
+    inp = x.astype(np.float32)
+    for k, (w_ih, w_hh, b_ih, b_hh) in enumerate(params):
+        if kind == "gru":
+            h = gru_cell(inp, h0[k], w_ih, w_hh, b_ih, b_hh)
+        elif kind == "rnn":
+            h = rnn_cell(inp, h0[k], w_ih, w_hh, b_ih, b_hh)
+        elif kind == "lstm":
+            h, c = lstm_cell(inp, h0[k], c0[k], w_ih, w_hh, b_ih, b_hh)
+            cs.append(c)
+        else:
+            raise ValueError(kind)
+        hs.append(h)
+        inp = h
+    if kind == "lstm":
+        return inp, np.stack(hs), np.stack(cs)
+    return inp, np.stack(hs)
+
+
+def mlp_forward(x, layers, training: bool = False, eps: float = 1e-5):
+    """MLP of torch/simpleDecoder.py:45-79 with dropout inactive.
+    layers: list of dicts {'w','b'} for Linear and {'gamma','beta','mean','var'} for BatchNorm1d,
+    in module order.  training=True uses batch statistics (biased variance)."""
+    h = x.astype(np.float32)
+    for ly in layers:
+        if "w" in ly:
+            h = (h @ ly["w"].T + ly["b"]).astype(np.float32)
+        elif "gamma" in ly:
+            if training:
+                mean = h.mean(0)
+                var = h.var(0)
+            else:
+                mean, var = ly["mean"], ly["var"]
+            h = ((h - mean) / np.sqrt(var + eps) * ly["gamma"] + ly["beta"]).astype(np.float32)
+            h = np.maximum(h, 0)  # the ReLU that follows every BatchNorm1d
+    return h
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def powerlaw_snapshot(n: int, e: int, t: int = 0, k_dst: float = 3.0, k_src: float = 1.5,
+                      perm: Optional[np.ndarray] = None):
+    """Synthetic power-law snapshot: dst = pi(floor(n*u1^k_dst)), src = pi(floor(n*u2^k_src)),
+    u ~ U[0,1) from PCG64(1234+t); pi is a fixed permutation (seed 99).  Multi-edges and
+    self-loops are kept, as DGL keeps them."""
+    rng = np.random.Generator(np.random.PCG64(1234 + t))
+    if perm is None:
+        perm = np.random.Generator(np.random.PCG64(99)).permutation(n)
+    dst = perm[np.minimum((n * rng.random(e) ** k_dst).astype(np.int64), n - 1)]
+    src = perm[np.minimum((n * rng.random(e) ** k_src).astype(np.int64), n - 1)]
+    return src.astype(np.int64), dst.astype(np.int64)

@@ -1,0 +1,96 @@
+"""ctypes binding of libspmi.so, the C-ABI HIP library (include/spmi.h).
+
+There is no CPU fallback: if the shared library is missing, every entry point raises.
+Pointers are raw device addresses (`tensor.data_ptr()`), the stream is torch's current
+HIP stream; torch's caching allocator owns all memory.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libspmi.so")
+_lib: Optional[ctypes.CDLL] = None
+
+c_i64, c_i32, c_int, c_f32, c_vp, c_sz = (
+    ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/spmi.h one to one
+_SIGNATURES = {
+    "spmi_version": (c_int, []),
+    "spmi_last_error": (ctypes.c_char_p, []),
+    "spmi_degree_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "spmi_degree": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "spmi_coo_to_csr_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "spmi_coo_to_csr": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                c_vp, c_vp]),
+    "spmi_norm_from_indptr": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "spmi_spmm_plan": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "spmi_gcn_spmm": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp,
+                              c_vp, c_vp, c_int, c_f32, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32,
+                              c_i32, c_i32, c_vp, c_vp]),
+    "spmi_act_bias_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp]),
+    "spmi_gather_rows": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "spmi_gru_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
+                                  c_vp, c_vp]),
+    "spmi_gru_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "spmi_lstm_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
+                                   c_vp, c_int, c_vp, c_vp]),
+    "spmi_lstm_gate_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "spmi_rnn_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
+                                  c_vp]),
+    "spmi_rnn_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class SpmiError(RuntimeError):
+    """A libspmi entry point returned a negative status."""
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load libspmi.so (once).  Raises if it has not been built: the product path has no
+    other implementation to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SpmiError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950); spiral_amd has no CPU fallback")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().spmi_last_error()
+        raise SpmiError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SpmiError(
+                "spiral_amd kernels run on the GPU only (got a CPU tensor); there is no CPU path")

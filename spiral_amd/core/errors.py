@@ -1,0 +1,16 @@
+"""Exception types raised on the snapshot path; names follow spiro/core/errors.py:18-31."""
+
+
+class DimensionError(Exception):
+    """An input table has fewer columns than the container needs."""
+
+
+class ValueNotSortedError(Exception):
+    """A table or the timestamp index is not sorted by time."""
+
+
+class GraphError(Exception):
+    """Raised where the reference surfaces dgl.DGLError (invalid norm, zero in-degree...)."""
+
+
+DGLError = GraphError

@@ -1,0 +1,540 @@
+// Snapshot graph container kernels for gfx950: degrees, COO -> CSR, gcn norm and
+// the load-balance plan of the aggregation.
+//
+// What they replace in the reference: dgl.graph((src,dst)) and DGL's lazy
+// COOToCSR reached from spiro/dtdg/types.py:191, DGLGraph.in_degrees()
+// (types.py:241) and the degree/norm lines of dgl GraphConv.forward (call sites
+// spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:113,116).
+//
+// Design: one stable LSB radix sort of (key = row id, value = edge position)
+// with digits of at most 8 bits.  Per pass: a per-tile digit histogram, a
+// per-digit scan over tiles, and a scatter that ranks keys inside the tile with
+// wave ballots (stable, no atomics on the data path), stages the tile in LDS in
+// digit order and writes each digit run coalesced.  Row pointers then fall out
+// of the sorted keys as run boundaries, so degrees need no atomics either and
+// every output is bit-reproducible.  All of it is HBM-bound integer work.
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kKeysPerThread = 16;
+constexpr int kTile = kThreads * kKeysPerThread;  // keys per workgroup per pass
+constexpr int kMaxDigits = 256;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// Keys enter as the caller's int64 node ids (first pass) or as the library's
+// own validated uint32 keys (later passes).  An id outside [0,N) raises the
+// status word and is clamped so that no later access leaves a buffer.
+template <typename T>
+__device__ __forceinline__ uint32_t checked_key(T raw, uint32_t n, int32_t* status) {
+  if constexpr (sizeof(T) == 8) {
+    if (static_cast<uint64_t>(raw) >= static_cast<uint64_t>(n)) {
+      *status = 1;
+      return n - 1;
+    }
+    return static_cast<uint32_t>(raw);
+  } else {
+    return static_cast<uint32_t>(raw);
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread workgroup.
+// s_wave needs kWaves entries; *total receives the workgroup sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave,
+                                                         uint32_t* total) {
+  uint32_t incl = wave_inclusive_scan(v);
+  if (lane_id() == 63) s_wave[wave_id()] = incl;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    uint32_t c = s_wave[w];
+    if (w < wave_id()) base += c;
+    sum += c;
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// ---- pass kernel 1: per-tile digit histogram ------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void radix_hist_kernel(const KeyT* __restrict__ keys,
+                                                              int64_t E, uint32_t N, int shift,
+                                                              int bits, uint32_t* __restrict__ hist,
+                                                              int n_tiles, int32_t* status) {
+  __shared__ uint32_t s_hist[kMaxDigits];
+  const int ndig = 1 << bits;
+  const uint32_t mask = ndig - 1;
+  for (int d = threadIdx.x; d < ndig; d += kThreads) s_hist[d] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+#pragma unroll 4
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    int64_t i = base + j * kThreads + threadIdx.x;
+    if (i < E) {
+      uint32_t k = checked_key(keys[i], N, status);
+      atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < ndig; d += kThreads)
+    hist[static_cast<size_t>(d) * n_tiles + blockIdx.x] = s_hist[d];
+}
+
+// ---- pass kernel 2: one workgroup per digit scans that digit's tile counts ------
+__global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist,
+                                                              int n_tiles,
+                                                              uint32_t* __restrict__ totals) {
+  __shared__ uint32_t s_wave[kWaves];
+  uint32_t* row = hist + static_cast<size_t>(blockIdx.x) * n_tiles;
+  const int per = (n_tiles + kThreads - 1) / kThreads;
+  const int begin = min(static_cast<int>(threadIdx.x) * per, n_tiles);
+  const int end = min(begin + per, n_tiles);
+  uint32_t sum = 0;
+  for (int i = begin; i < end; ++i) sum += row[i];
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(sum, s_wave, &total);
+  for (int i = begin; i < end; ++i) {
+    uint32_t c = row[i];
+    row[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+// ---- pass kernel 3: stable scatter ------------------------------------------------
+// FIRST: keys come from the caller (range-checked) and the value is the key's
+// position.  HAS_VAL: carry a 32-bit value with each key.
+template <typename KeyT, bool FIRST, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
+    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t E, uint32_t N,
+    int shift, int bits, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+    int n_tiles, int32_t* status) {
+  __shared__ uint32_t s_cnt[kWaves][kMaxDigits];
+  __shared__ uint32_t s_dstart[kMaxDigits];
+  __shared__ uint32_t s_goff[kMaxDigits];
+  __shared__ uint32_t s_wave[kWaves];
+  __shared__ uint32_t s_keys[kTile];
+  __shared__ uint32_t s_vals[HAS_VAL ? kTile : 1];
+
+  const int ndig = 1 << bits;
+  const uint32_t mask = ndig - 1;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int tid = threadIdx.x;
+
+  for (int d = tid; d < kWaves * kMaxDigits; d += kThreads) (&s_cnt[0][0])[d] = 0;
+  __syncthreads();
+
+  const int64_t tile_base = static_cast<int64_t>(blockIdx.x) * kTile;
+  const int64_t wave_base = tile_base + static_cast<int64_t>(wave) * 64 * kKeysPerThread;
+  const int64_t tile_left = E - tile_base;
+  const int tile_count = tile_left < kTile ? static_cast<int>(tile_left) : kTile;
+
+  uint32_t key[kKeysPerThread];
+  uint32_t val[kKeysPerThread];
+  uint32_t rank[kKeysPerThread];
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = wave_base + j * 64 + lane;
+    const bool valid = i < E;
+    uint32_t k = 0, v = 0;
+    if (valid) {
+      k = checked_key(keys_in[i], N, status);
+      if constexpr (HAS_VAL) v = FIRST ? static_cast<uint32_t>(i) : vals_in[i];
+    }
+    key[j] = k;
+    val[j] = v;
+    const uint32_t d = (k >> shift) & mask;
+    // lanes of this wave row that hold the same digit
+    uint64_t same = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(valid && bit);
+      same &= bit ? bal : ~bal;
+    }
+    const uint32_t below = __popcll(same & lanes_below);
+    uint32_t prev = 0;
+    if (valid) prev = s_cnt[wave][d];
+    rank[j] = prev + below;
+    if (valid && below == 0) s_cnt[wave][d] = prev + static_cast<uint32_t>(__popcll(same));
+  }
+  __syncthreads();
+
+  // per digit: exclusive prefix over waves, tile total, tile-local digit start
+  uint32_t tile_total_d = 0;
+  if (tid < ndig) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      uint32_t c = s_cnt[w][tid];
+      s_cnt[w][tid] = run;
+      run += c;
+    }
+    tile_total_d = run;
+  }
+  uint32_t unused;
+  const uint32_t dstart = block_exclusive_scan(tile_total_d, s_wave, &unused);
+  const uint32_t gtot = (tid < ndig) ? totals[tid] : 0u;
+  const uint32_t gbase = block_exclusive_scan(gtot, s_wave, &unused);
+  if (tid < ndig) {
+    s_dstart[tid] = dstart;
+    s_goff[tid] = gbase + hist[static_cast<size_t>(tid) * n_tiles + blockIdx.x];
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = wave_base + j * 64 + lane;
+    if (i < E) {
+      const uint32_t d = (key[j] >> shift) & mask;
+      const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[j];
+      s_keys[pos] = key[j];
+      if constexpr (HAS_VAL) s_vals[pos] = val[j];
+    }
+  }
+  __syncthreads();
+
+#pragma unroll 4
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int i = j * kThreads + tid;
+    if (i < tile_count) {
+      const uint32_t k = s_keys[i];
+      const uint32_t d = (k >> shift) & mask;
+      const uint32_t g = s_goff[d] + (static_cast<uint32_t>(i) - s_dstart[d]);
+      keys_out[g] = k;
+      if constexpr (HAS_VAL) vals_out[g] = s_vals[i];
+    }
+  }
+}
+
+// ---- row pointers from sorted keys (+ gather of the other endpoint) ---------------
+// Position i starts every row in (keys[i-1], keys[i]].  Short gaps are written by
+// the lane itself; long gaps (many consecutive empty rows) are filled by the
+// whole wave so that one lane never writes a long run alone.
+__device__ __forceinline__ void wave_fill_gaps(int32_t* indptr, int64_t start, int64_t count,
+                                               int32_t value) {
+  const int lane = lane_id();
+  uint64_t m = __ballot(count > 0);
+  while (m) {
+    const int src_lane = __ffsll(static_cast<unsigned long long>(m)) - 1;
+    m &= m - 1;
+    const int64_t s = __shfl(start, src_lane);
+    const int64_t n = __shfl(count, src_lane);
+    const int32_t v = __shfl(value, src_lane);
+    for (int64_t r = lane; r < n; r += 64) indptr[s + r] = v;
+  }
+}
+
+template <typename OtherT, bool HAS_OTHER>
+__global__ __launch_bounds__(kThreads) void csr_finalize_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ eid,
+    const OtherT* __restrict__ other, int64_t E, int64_t N, uint32_t n_other,
+    int32_t* __restrict__ indptr, int32_t* __restrict__ indices, int32_t* status) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const bool valid = i < E;
+  int64_t k = 0, prev = -1;
+  if (valid) {
+    k = keys[i];
+    if (i > 0) prev = keys[i - 1];
+  }
+  int64_t gap_start = prev + 1;
+  int64_t gap = valid ? (k - prev) : 0;
+  if (gap > 0 && gap <= 4) {
+    for (int64_t r = 0; r < gap; ++r) indptr[gap_start + r] = static_cast<int32_t>(i);
+    gap = 0;
+  }
+  wave_fill_gaps(indptr, gap_start, gap, static_cast<int32_t>(i));
+  // rows after the last key (and indptr[N]) point at E
+  const bool last = valid && (i == E - 1);
+  wave_fill_gaps(indptr, k + 1, last ? (N - k) : 0, static_cast<int32_t>(E));
+  if constexpr (HAS_OTHER) {
+    if (valid) indices[i] = static_cast<int32_t>(checked_key(other[eid[i]], n_other, status));
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void indptr_to_degree_kernel(const int32_t* __restrict__ indptr, int64_t N,
+                                        int64_t* __restrict__ deg) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < N) deg[i] = static_cast<int64_t>(indptr[i + 1]) - static_cast<int64_t>(indptr[i]);
+}
+
+__global__ void norm_kernel(const int32_t* __restrict__ indptr, int64_t N, int mode,
+                            float* __restrict__ norm) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < N) {
+    float d = static_cast<float>(indptr[i + 1] - indptr[i]);
+    d = fmaxf(d, 1.0f);
+    norm[i] = (mode == SPMI_NORM_RSQRT) ? (1.0f / sqrtf(d)) : (1.0f / d);
+  }
+}
+
+// ---- aggregation plan ---------------------------------------------------------------
+__global__ void plan_collect_kernel(const int32_t* __restrict__ indptr, int64_t N,
+                                    int32_t heavy_thresh, int32_t* __restrict__ heavy_rows,
+                                    int64_t capacity, int32_t* counts) {
+  int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < N) {
+    int32_t deg = indptr[r + 1] - indptr[r];
+    if (deg > heavy_thresh) {
+      int32_t pos = atomicAdd(&counts[0], 1);
+      if (pos < capacity) heavy_rows[pos] = static_cast<int32_t>(r);
+    }
+  }
+}
+
+// Turns the collected list into chunk offsets: heavy_chunk_ptr = exclusive scan of
+// ceil(deg/chunk).  The list is in arrival order of the atomic append; results of
+// the aggregation do not depend on that order (each row is reduced on its own).
+__global__ __launch_bounds__(kThreads) void plan_finish_kernel(
+    const int32_t* __restrict__ indptr, int32_t chunk, const int32_t* __restrict__ heavy_rows,
+    int32_t* __restrict__ heavy_chunk_ptr, int64_t capacity, int32_t* counts) {
+  __shared__ uint32_t s_wave[kWaves];
+  __shared__ uint32_t s_carry;
+  const int64_t collected = counts[0];
+  const int n = static_cast<int>(collected < capacity ? collected : capacity);
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += kThreads) {
+    const int i = base + threadIdx.x;
+    uint32_t c = 0;
+    if (i < n) {
+      const int32_t r = heavy_rows[i];
+      const int32_t deg = indptr[r + 1] - indptr[r];
+      c = static_cast<uint32_t>((deg + chunk - 1) / chunk);
+    }
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(c, s_wave, &total);
+    const uint32_t carry = s_carry;
+    if (i < n) heavy_chunk_ptr[i] = static_cast<int32_t>(carry + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    heavy_chunk_ptr[n] = static_cast<int32_t>(s_carry);
+    counts[0] = n;
+    counts[1] = static_cast<int32_t>(s_carry);
+  }
+}
+
+// ---- host-side sort driver ------------------------------------------------------------
+struct SortShape {
+  int passes;
+  int pass_bits[4];
+  int n_tiles;
+};
+
+SortShape sort_shape(int64_t E, int64_t N) {
+  SortShape s{};
+  int bits = 1;
+  while ((int64_t{1} << bits) < N) ++bits;
+  s.passes = (bits + 7) / 8;
+  const int base = bits / s.passes, rem = bits % s.passes;
+  for (int p = 0; p < s.passes; ++p) s.pass_bits[p] = base + (p < rem ? 1 : 0);
+  s.n_tiles = static_cast<int>((E + kTile - 1) / kTile);
+  return s;
+}
+
+struct SortBuffers {
+  uint32_t* keys[2];
+  uint32_t* vals[2];  // vals[0] is the caller's eid output
+  uint32_t* hist;
+  uint32_t* totals;
+};
+
+// Sorts E keys; the result lands in keys[0] / vals[0].
+template <bool HAS_VAL>
+int run_sort(const int64_t* keys_in, int64_t E, int64_t N, const SortShape& sh,
+             const SortBuffers& b, int32_t* status, hipStream_t stream) {
+  int shift = 0;
+  for (int p = 0; p < sh.passes; ++p) {
+    const int bits = sh.pass_bits[p];
+    const int out = (sh.passes - 1 - p) & 1;
+    const int in = out ^ 1;
+    const dim3 grid(sh.n_tiles), block(kThreads);
+    if (p == 0) {
+      radix_hist_kernel<int64_t><<<grid, block, 0, stream>>>(keys_in, E, (uint32_t)N, shift, bits,
+                                                             b.hist, sh.n_tiles, status);
+    } else {
+      radix_hist_kernel<uint32_t><<<grid, block, 0, stream>>>(b.keys[in], E, (uint32_t)N, shift,
+                                                              bits, b.hist, sh.n_tiles, status);
+    }
+    SPMI_CHECK_LAUNCH("radix_hist");
+    radix_scan_kernel<<<dim3(1 << bits), block, 0, stream>>>(b.hist, sh.n_tiles, b.totals);
+    SPMI_CHECK_LAUNCH("radix_scan");
+    if (p == 0) {
+      radix_scatter_kernel<int64_t, true, HAS_VAL><<<grid, block, 0, stream>>>(
+          keys_in, nullptr, b.keys[out], b.vals[out], E, (uint32_t)N, shift, bits, b.hist,
+          b.totals, sh.n_tiles, status);
+    } else {
+      radix_scatter_kernel<uint32_t, false, HAS_VAL><<<grid, block, 0, stream>>>(
+          b.keys[in], b.vals[in], b.keys[out], b.vals[out], E, (uint32_t)N, shift, bits, b.hist,
+          b.totals, sh.n_tiles, status);
+    }
+    SPMI_CHECK_LAUNCH("radix_scatter");
+    shift += bits;
+  }
+  return SPMI_OK;
+}
+
+int check_sizes(int64_t E, int64_t N, const char* who) {
+  SPMI_REQUIRE(E >= 0 && N >= 1, SPMI_ERR_INVALID_ARG, "%s: need E >= 0 and N >= 1 (E=%lld N=%lld)",
+               who, (long long)E, (long long)N);
+  SPMI_REQUIRE(E < (int64_t{1} << 31) && N < (int64_t{1} << 31), SPMI_ERR_UNSUPPORTED,
+               "%s: E=%lld or N=%lld exceeds the int32 on-device CSR limit", who, (long long)E,
+               (long long)N);
+  return SPMI_OK;
+}
+
+size_t sort_scratch_bytes(int64_t E, int64_t N) {
+  const SortShape sh = sort_shape(E, N);
+  return spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256) +
+         spmi::align_up(sizeof(uint32_t) * kMaxDigits, 256);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t spmi_coo_to_csr_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 1) return 0;
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  return 3 * e4 + sort_scratch_bytes(E, N);
+}
+
+int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
+                    int64_t N_other, int32_t* indptr, int32_t* indices, int32_t* eid, void* ws,
+                    size_t ws_bytes, int32_t* status, void* stream) {
+  if (int rc = check_sizes(E, N, "spmi_coo_to_csr")) return rc;
+  SPMI_REQUIRE(N_other >= 1 && N_other < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
+               "spmi_coo_to_csr: bad N_other=%lld", (long long)N_other);
+  SPMI_REQUIRE(indptr && status, SPMI_ERR_INVALID_ARG, "spmi_coo_to_csr: null indptr/status");
+  hipStream_t st = spmi::as_stream(stream);
+  if (E == 0) {
+    SPMI_CHECK_HIP(hipMemsetAsync(indptr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+    return SPMI_OK;
+  }
+  SPMI_REQUIRE(key && other && indices && eid && ws, SPMI_ERR_INVALID_ARG,
+               "spmi_coo_to_csr: null pointer argument");
+  SPMI_REQUIRE(ws_bytes >= spmi_coo_to_csr_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
+               "spmi_coo_to_csr: workspace %zu < required %zu", ws_bytes,
+               spmi_coo_to_csr_workspace_bytes(E, N));
+  const SortShape sh = sort_shape(E, N);
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  char* p = static_cast<char*>(ws);
+  SortBuffers b{};
+  b.keys[0] = reinterpret_cast<uint32_t*>(p);
+  b.keys[1] = reinterpret_cast<uint32_t*>(p + e4);
+  b.vals[0] = reinterpret_cast<uint32_t*>(eid);
+  b.vals[1] = reinterpret_cast<uint32_t*>(p + 2 * e4);
+  b.hist = reinterpret_cast<uint32_t*>(p + 3 * e4);
+  b.totals = reinterpret_cast<uint32_t*>(
+      p + 3 * e4 + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
+  if (int rc = run_sort<true>(key, E, N, sh, b, status, st)) return rc;
+  const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
+  csr_finalize_kernel<int64_t, true><<<grid, kThreads, 0, st>>>(
+      b.keys[0], b.vals[0], other, E, N, (uint32_t)N_other, indptr, indices, status);
+  SPMI_CHECK_LAUNCH("csr_finalize");
+  return SPMI_OK;
+}
+
+size_t spmi_degree_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 1) return 0;
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  return 2 * e4 + spmi::align_up(sizeof(int32_t) * (size_t)(N + 1), 256) + sort_scratch_bytes(E, N);
+}
+
+int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws, size_t ws_bytes,
+                int32_t* status, void* stream) {
+  if (int rc = check_sizes(E, N, "spmi_degree")) return rc;
+  SPMI_REQUIRE(deg && status, SPMI_ERR_INVALID_ARG, "spmi_degree: null deg/status");
+  hipStream_t st = spmi::as_stream(stream);
+  if (E == 0) {
+    SPMI_CHECK_HIP(hipMemsetAsync(deg, 0, sizeof(int64_t) * (size_t)N, st));
+    return SPMI_OK;
+  }
+  SPMI_REQUIRE(ids && ws, SPMI_ERR_INVALID_ARG, "spmi_degree: null pointer argument");
+  SPMI_REQUIRE(ws_bytes >= spmi_degree_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
+               "spmi_degree: workspace %zu < required %zu", ws_bytes,
+               spmi_degree_workspace_bytes(E, N));
+  const SortShape sh = sort_shape(E, N);
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  const size_t np = spmi::align_up(sizeof(int32_t) * (size_t)(N + 1), 256);
+  char* p = static_cast<char*>(ws);
+  SortBuffers b{};
+  b.keys[0] = reinterpret_cast<uint32_t*>(p);
+  b.keys[1] = reinterpret_cast<uint32_t*>(p + e4);
+  b.vals[0] = b.vals[1] = nullptr;
+  int32_t* indptr = reinterpret_cast<int32_t*>(p + 2 * e4);
+  b.hist = reinterpret_cast<uint32_t*>(p + 2 * e4 + np);
+  b.totals = reinterpret_cast<uint32_t*>(
+      p + 2 * e4 + np + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
+  if (int rc = run_sort<false>(ids, E, N, sh, b, status, st)) return rc;
+  const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
+  csr_finalize_kernel<int64_t, false><<<grid, kThreads, 0, st>>>(
+      b.keys[0], nullptr, nullptr, E, N, 0u, indptr, nullptr, status);
+  SPMI_CHECK_LAUNCH("csr_finalize(degree)");
+  indptr_to_degree_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, deg);
+  SPMI_CHECK_LAUNCH("indptr_to_degree");
+  return SPMI_OK;
+}
+
+int spmi_norm_from_indptr(const int32_t* indptr, int64_t N, int mode, float* norm, void* stream) {
+  SPMI_REQUIRE(indptr && norm, SPMI_ERR_INVALID_ARG, "spmi_norm_from_indptr: null pointer");
+  SPMI_REQUIRE(N >= 0 && N < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
+               "spmi_norm_from_indptr: bad N=%lld", (long long)N);
+  SPMI_REQUIRE(mode == SPMI_NORM_RSQRT || mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
+               "spmi_norm_from_indptr: bad mode %d", mode);
+  if (N == 0) return SPMI_OK;
+  norm_kernel<<<(int)((N + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(indptr, N, mode, norm);
+  SPMI_CHECK_LAUNCH("norm");
+  return SPMI_OK;
+}
+
+int spmi_spmm_plan(const int32_t* indptr, int64_t N, int32_t heavy_thresh, int32_t chunk,
+                   int32_t* heavy_rows, int32_t* heavy_chunk_ptr, int64_t capacity,
+                   int32_t* counts, void* stream) {
+  SPMI_REQUIRE(indptr && heavy_rows && heavy_chunk_ptr && counts, SPMI_ERR_INVALID_ARG,
+               "spmi_spmm_plan: null pointer");
+  SPMI_REQUIRE(N >= 0 && N < (int64_t{1} << 31) && heavy_thresh >= 1 && chunk >= 1 &&
+                   capacity >= 2,
+               SPMI_ERR_INVALID_ARG, "spmi_spmm_plan: bad sizes");
+  hipStream_t st = spmi::as_stream(stream);
+  SPMI_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
+  if (N > 0) {
+    plan_collect_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, heavy_thresh,
+                                                                heavy_rows, capacity - 1, counts);
+    SPMI_CHECK_LAUNCH("plan_collect");
+  }
+  plan_finish_kernel<<<1, kThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr,
+                                             capacity - 1, counts);
+  SPMI_CHECK_LAUNCH("plan_finish");
+  return SPMI_OK;
+}
+
+}  // extern "C"

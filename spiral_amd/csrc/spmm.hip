@@ -1,0 +1,412 @@
+// Fused normalised aggregation for gfx950:
+//
+//   Y[r,:] = act( dst_scale[r] * sum_{j in row r} w_j * X[indices[j],:] + bias )
+//
+// Replaces, in one kernel, the source scaling, update_all(copy_u|u_mul_e, sum),
+// destination scaling, bias and activation of dgl GraphConv.forward as called at
+// spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:113,116.
+//
+// Mapping.  HBM-bound gather: every nonzero pulls one F-wide source row, so the
+// kernel is built around whole-row, fully coalesced wave loads and many of them
+// in flight.  One 64-lane wave owns a block of consecutive destination rows; the
+// nonzeros of such a block are one contiguous CSR range, which the wave walks as
+// a flat stream: 64 neighbour ids per coalesced index load, kept in a VGPR and
+// broadcast with v_readlane (scalar row base + lane offset addressing), U source
+// rows loaded before the first is consumed, row boundaries handled by
+// wave-uniform scalar compares.  Short and empty rows therefore cost no idle
+// load slots.  Rows heavier than `heavy_thresh` are skipped here and summed
+// chunk-wise by whole workgroups (spmm_heavy_kernel + spmm_heavy_reduce_kernel)
+// so that a hub row is spread over the chip.  No atomics anywhere: sums are in
+// CSR order inside a row (fixed chunk order for hub rows), bit-reproducible.
+
+#include "common.h"
+
+#include <climits>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / 64;
+constexpr int kUnroll = 8;  // source rows in flight per wave
+
+template <int VEC>
+struct VecOf;
+template <>
+struct VecOf<1> {
+  using type = float;
+};
+template <>
+struct VecOf<2> {
+  using type = float __attribute__((ext_vector_type(2)));
+};
+template <>
+struct VecOf<4> {
+  using type = float __attribute__((ext_vector_type(4)));
+};
+
+struct SpmmParams {
+  const int32_t* indptr;
+  const int32_t* indices;
+  const float* X;
+  const float* src_scale;
+  const float* edge_w;
+  const float* dst_scale;
+  const float* bias;
+  float* Y;
+  int64_t ldx, ldy;
+  int32_t n_rows;
+  int32_t F;
+  int32_t rows_per_wave;
+  int32_t act;
+  float slope;
+  int32_t heavy_thresh;
+};
+
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::type activate(typename VecOf<VEC>::type y, int act,
+                                                              float slope) {
+  if (act == SPMI_ACT_NONE) return y;
+  const float neg = (act == SPMI_ACT_RELU) ? 0.0f : slope;
+  if constexpr (VEC == 1) {
+    return y > 0.0f ? y : y * neg;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y[i] = y[i] > 0.0f ? y[i] : y[i] * neg;
+    return y;
+  }
+}
+
+// Sum of w_j * X[indices[j]] over the CSR range [s,e) as seen by one wave, with a
+// callback at every row boundary.  `row_end_of(row)` returns indptr of row+1 and
+// `flush(row, acc)` consumes a finished row; both are wave-uniform.
+template <int VEC, typename RowEnd, typename Flush>
+__device__ __forceinline__ void stream_range(const SpmmParams& p, const float* __restrict__ xcol,
+                                             bool fok, int lane, int s, int e, int row,
+                                             int row_last, RowEnd row_end_of, Flush flush) {
+  using V = typename VecOf<VEC>::type;
+  V acc = V(0.0f);
+  int row_end = row_end_of(row);
+  const bool weighted = (p.src_scale != nullptr) || (p.edge_w != nullptr);
+  for (int base = s; base < e; base += 64) {
+    const int cnt = min(64, e - base);
+    int my = 0;
+    float w = 1.0f;
+    if (lane < cnt) {
+      my = p.indices[base + lane];
+      if (p.edge_w) w = p.edge_w[base + lane];
+      if (p.src_scale) w *= p.src_scale[my];
+    }
+    for (int k = 0; k < cnt; k += kUnroll) {
+      V v[kUnroll];
+      float wk[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int kk = min(k + u, cnt - 1);
+        const int src = readlane_i(my, kk);
+        wk[u] = weighted ? readlane_f(w, kk) : 1.0f;
+        v[u] = V(0.0f);
+        if (fok) v[u] = *reinterpret_cast<const V*>(xcol + static_cast<int64_t>(src) * p.ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (k + u < cnt) {
+          const int pos = base + k + u;
+          while (pos == row_end) {
+            flush(row, acc);
+            acc = V(0.0f);
+            ++row;
+            row_end = row_end_of(row);
+          }
+          acc += wk[u] * v[u];
+        }
+      }
+    }
+  }
+  while (row <= row_last) {
+    flush(row, acc);
+    acc = V(0.0f);
+    ++row;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
+  using V = typename VecOf<VEC>::type;
+  const int lane = threadIdx.x & 63;
+  const int wave =
+      __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)));
+  const int R = p.rows_per_wave;
+  const int64_t r0_64 = static_cast<int64_t>(wave) * R;
+  if (r0_64 >= p.n_rows) return;
+  const int r0 = static_cast<int>(r0_64);
+  const int nr = min(R, p.n_rows - r0);
+  const int f = (static_cast<int>(blockIdx.y) * 64 + lane) * VEC;
+  const bool fok = f < p.F;
+
+  // lane i holds indptr[r0+i] (i <= nr) and the destination scale of row r0+i
+  const int ip = p.indptr[r0 + min(lane, nr)];
+  float dsl = 1.0f;
+  if (p.dst_scale && lane < nr) dsl = p.dst_scale[r0 + lane];
+  V bias = V(0.0f);
+  if (p.bias && fok) bias = *reinterpret_cast<const V*>(p.bias + f);
+  const int ip_next = __shfl_down(ip, 1);
+  const bool heavy_lane = (lane < nr) && (ip_next - ip > p.heavy_thresh);
+  const bool any_heavy = __ballot(heavy_lane) != 0ull;
+
+  const float* xcol = p.X + f;
+  float* ycol = p.Y + f;
+  auto row_end_of = [&](int row) { return readlane_i(ip, row + 1); };
+  auto flush = [&](int row, V acc) {
+    const float ds = readlane_f(dsl, row);
+    V y = activate<VEC>(acc * ds + bias, p.act, p.slope);
+    if (fok) *reinterpret_cast<V*>(ycol + static_cast<int64_t>(r0 + row) * p.ldy) = y;
+  };
+
+  if (!any_heavy) {
+    stream_range<VEC>(p, xcol, fok, lane, readlane_i(ip, 0), readlane_i(ip, nr), 0, nr - 1,
+                      row_end_of, flush);
+  } else {
+    for (int row = 0; row < nr; ++row) {
+      const int rs = readlane_i(ip, row), re = readlane_i(ip, row + 1);
+      if (re - rs > p.heavy_thresh) continue;  // summed by the heavy-row kernels
+      stream_range<VEC>(p, xcol, fok, lane, rs, re, row, row, row_end_of, flush);
+    }
+  }
+}
+
+// One workgroup sums one chunk of a heavy row; its four waves take a quarter of
+// the chunk each and are combined through LDS in wave order.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void spmm_heavy_kernel(SpmmParams p,
+                                                              const int32_t* __restrict__ heavy_rows,
+                                                              const int32_t* __restrict__ chunk_ptr,
+                                                              int n_heavy, int chunk,
+                                                              float* __restrict__ partial) {
+  using V = typename VecOf<VEC>::type;
+  __shared__ V s_part[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int c = blockIdx.x;
+  int lo = 0, hi = n_heavy;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_ptr[mid] <= c) lo = mid; else hi = mid;
+  }
+  const int row = heavy_rows[lo];
+  const int k = c - chunk_ptr[lo];
+  const int row_end = p.indptr[row + 1];
+  const int cs = p.indptr[row] + k * chunk;
+  const int ce = min(row_end, cs + chunk);
+  const int per = (chunk + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int s = min(ce, cs + wave * per);
+  const int e = min(ce, s + per);
+  const int f = (static_cast<int>(blockIdx.y) * 64 + lane) * VEC;
+  const bool fok = f < p.F;
+
+  V total = V(0.0f);
+  auto row_end_of = [&](int) { return INT_MAX; };
+  auto flush = [&](int, V acc) { total = acc; };
+  stream_range<VEC>(p, p.X + f, fok, lane, s, e, 0, 0, row_end_of, flush);
+  s_part[wave][lane] = total;
+  __syncthreads();
+  if (wave == 0 && fok) {
+    V sum = s_part[0][lane];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) sum += s_part[w][lane];
+    *reinterpret_cast<V*>(partial + static_cast<int64_t>(c) * p.F + f) = sum;
+  }
+}
+
+// One workgroup finishes one heavy row: partial sums are added in a fixed order
+// (wave w takes chunks w, w+4, ...; waves combined in wave order), then the
+// same epilogue as the stream kernel.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void spmm_heavy_reduce_kernel(
+    SpmmParams p, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ chunk_ptr,
+    const float* __restrict__ partial) {
+  using V = typename VecOf<VEC>::type;
+  __shared__ V s_part[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int h = blockIdx.x;
+  const int row = heavy_rows[h];
+  const int c0 = chunk_ptr[h], c1 = chunk_ptr[h + 1];
+  const int f = (static_cast<int>(blockIdx.y) * 64 + lane) * VEC;
+  const bool fok = f < p.F;
+  V acc = V(0.0f);
+  if (fok) {
+    const float* base = partial + f;
+    int c = c0 + wave;
+    for (; c + 3 * kWavesPerBlock < c1; c += 4 * kWavesPerBlock) {
+      V a0 = *reinterpret_cast<const V*>(base + static_cast<int64_t>(c) * p.F);
+      V a1 = *reinterpret_cast<const V*>(base + static_cast<int64_t>(c + kWavesPerBlock) * p.F);
+      V a2 = *reinterpret_cast<const V*>(base + static_cast<int64_t>(c + 2 * kWavesPerBlock) * p.F);
+      V a3 = *reinterpret_cast<const V*>(base + static_cast<int64_t>(c + 3 * kWavesPerBlock) * p.F);
+      acc += a0;
+      acc += a1;
+      acc += a2;
+      acc += a3;
+    }
+    for (; c < c1; c += kWavesPerBlock)
+      acc += *reinterpret_cast<const V*>(base + static_cast<int64_t>(c) * p.F);
+  }
+  s_part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && fok) {
+    V sum = s_part[0][lane];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) sum += s_part[w][lane];
+    const float ds = p.dst_scale ? p.dst_scale[row] : 1.0f;
+    V bias = V(0.0f);
+    if (p.bias) bias = *reinterpret_cast<const V*>(p.bias + f);
+    V y = activate<VEC>(sum * ds + bias, p.act, p.slope);
+    *reinterpret_cast<V*>(p.Y + static_cast<int64_t>(row) * p.ldy + f) = y;
+  }
+}
+
+// gP = gY * act'(Y); gb[f] += sum over rows of gP[:,f].  A workgroup takes a slab
+// of rows and 64 columns; waves stride over the rows, lanes hold one column.
+constexpr int kBwdRowsPerBlock = 512;
+__global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __restrict__ gY,
+                                                                const float* __restrict__ Y,
+                                                                int64_t M, int F, int64_t ld,
+                                                                int act, float slope,
+                                                                float* __restrict__ gP,
+                                                                float* __restrict__ gb) {
+  __shared__ float s_col[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int f = blockIdx.y * 64 + lane;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBwdRowsPerBlock;
+  const int64_t row1 = row0 + kBwdRowsPerBlock < M ? row0 + kBwdRowsPerBlock : M;
+  const float neg = (act == SPMI_ACT_RELU) ? 0.0f : slope;
+  float col = 0.0f;
+  if (f < F) {
+    for (int64_t r = row0 + wave; r < row1; r += kWavesPerBlock) {
+      float g = gY[r * ld + f];
+      if (act != SPMI_ACT_NONE) g = (Y[r * ld + f] > 0.0f) ? g : g * neg;
+      gP[r * F + f] = g;
+      col += g;
+    }
+  }
+  if (gb) {
+    s_col[wave][lane] = col;
+    __syncthreads();
+    if (wave == 0 && f < F) {
+      float sum = s_col[0][lane] + s_col[1][lane] + s_col[2][lane] + s_col[3][lane];
+      atomicAdd(&gb[f], sum);
+    }
+  }
+}
+
+bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <int VEC>
+int launch_spmm(const SpmmParams& p, const int32_t* heavy_rows, const int32_t* chunk_ptr,
+                int n_heavy, int n_chunks, int chunk, float* partial, hipStream_t st) {
+  const unsigned fblocks = static_cast<unsigned>((p.F + 64 * VEC - 1) / (64 * VEC));
+  const int64_t n_waves = (static_cast<int64_t>(p.n_rows) + p.rows_per_wave - 1) / p.rows_per_wave;
+  const unsigned grid_x = static_cast<unsigned>((n_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+  spmm_stream_kernel<VEC><<<dim3(grid_x, fblocks), kThreads, 0, st>>>(p);
+  SPMI_CHECK_LAUNCH("spmm_stream");
+  if (n_heavy > 0) {
+    spmm_heavy_kernel<VEC><<<dim3(n_chunks, fblocks), kThreads, 0, st>>>(p, heavy_rows, chunk_ptr,
+                                                                        n_heavy, chunk, partial);
+    SPMI_CHECK_LAUNCH("spmm_heavy");
+    spmm_heavy_reduce_kernel<VEC><<<dim3(n_heavy, fblocks), kThreads, 0, st>>>(p, heavy_rows,
+                                                                              chunk_ptr, partial);
+    SPMI_CHECK_LAUNCH("spmm_heavy_reduce");
+  }
+  return SPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                  int64_t E, const float* X, int64_t ldx, int64_t F, const float* src_scale,
+                  const float* edge_w, const float* dst_scale, const float* bias, int act,
+                  float slope, float* Y, int64_t ldy, const int32_t* heavy_rows,
+                  const int32_t* heavy_chunk_ptr, int32_t n_heavy, int32_t n_chunks,
+                  int32_t heavy_thresh, int32_t chunk, float* partial_ws, void* stream) {
+  SPMI_REQUIRE(n_rows >= 0 && n_src >= 0 && E >= 0 && F >= 1, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm: bad sizes n_rows=%lld n_src=%lld E=%lld F=%lld", (long long)n_rows,
+               (long long)n_src, (long long)E, (long long)F);
+  SPMI_REQUIRE(n_rows < (int64_t{1} << 31) && n_src < (int64_t{1} << 31) &&
+                   E < (int64_t{1} << 31) && F < (int64_t{1} << 24),
+               SPMI_ERR_UNSUPPORTED, "spmi_gcn_spmm: size beyond the int32 on-device limits");
+  SPMI_REQUIRE(act >= SPMI_ACT_NONE && act <= SPMI_ACT_LEAKY_RELU, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm: bad activation code %d", act);
+  if (n_rows == 0) return SPMI_OK;
+  SPMI_REQUIRE(indptr && Y, SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: null indptr/Y");
+  SPMI_REQUIRE(E == 0 || (indices && X), SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: null indices/X");
+  SPMI_REQUIRE(ldx >= F && ldy >= F, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm: leading dimensions (%lld,%lld) smaller than F=%lld", (long long)ldx,
+               (long long)ldy, (long long)F);
+  SPMI_REQUIRE(n_heavy >= 0 && n_chunks >= n_heavy, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm: bad heavy plan (%d rows, %d chunks)", n_heavy, n_chunks);
+  if (n_heavy > 0) {
+    SPMI_REQUIRE(heavy_rows && heavy_chunk_ptr && partial_ws && heavy_thresh >= 1 && chunk >= 1,
+                 SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: heavy plan given without its buffers");
+  }
+
+  SpmmParams p{};
+  p.indptr = indptr;
+  p.indices = indices;
+  p.X = X;
+  p.src_scale = src_scale;
+  p.edge_w = edge_w;
+  p.dst_scale = dst_scale;
+  p.bias = bias;
+  p.Y = Y;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  p.n_rows = static_cast<int32_t>(n_rows);
+  p.F = static_cast<int32_t>(F);
+  p.act = act;
+  p.slope = slope;
+  p.heavy_thresh = (n_heavy > 0) ? heavy_thresh : INT_MAX;
+  // about 96 nonzeros per wave keeps the index load and the row stream busy
+  const int64_t avg_deg = (E + n_rows - 1) / n_rows;
+  int rpw = 32;
+  while (rpw > 2 && rpw * (avg_deg > 0 ? avg_deg : 1) > 128) rpw >>= 1;
+  p.rows_per_wave = rpw;
+
+  hipStream_t st = spmi::as_stream(stream);
+  const bool a16 = aligned(X, 16) && aligned(Y, 16) && (!bias || aligned(bias, 16)) &&
+                   (!partial_ws || aligned(partial_ws, 16)) && ldx % 4 == 0 && ldy % 4 == 0 &&
+                   F % 4 == 0;
+  const bool a8 = aligned(X, 8) && aligned(Y, 8) && (!bias || aligned(bias, 8)) &&
+                  (!partial_ws || aligned(partial_ws, 8)) && ldx % 2 == 0 && ldy % 2 == 0 &&
+                  F % 2 == 0;
+  if (F >= 256 && a16)
+    return launch_spmm<4>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
+  if (F >= 128 && a8)
+    return launch_spmm<2>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
+  return launch_spmm<1>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
+}
+
+int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
+                      float slope, float* gP, float* gb, void* stream) {
+  SPMI_REQUIRE(M >= 0 && F >= 1 && ld >= F && F < (int64_t{1} << 24), SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd: bad sizes");
+  SPMI_REQUIRE(act >= SPMI_ACT_NONE && act <= SPMI_ACT_LEAKY_RELU, SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd: bad activation code %d", act);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(gY && gP && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd: null pointer");
+  const unsigned gx = static_cast<unsigned>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);
+  const unsigned gy = static_cast<unsigned>((F + 63) / 64);
+  act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
+      gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
+  SPMI_CHECK_LAUNCH("act_bias_bwd");
+  return SPMI_OK;
+}
+
+}  // extern "C"

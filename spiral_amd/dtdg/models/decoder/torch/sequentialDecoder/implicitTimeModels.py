@@ -1,0 +1,210 @@
+"""Sequential decoders with per-node memory; API of
+spiro/dtdg/models/decoder/torch/sequentialDecoder/implicitTimeModels.py:28-286.
+
+The time recurrence runs across snapshot calls through NodeMemory (sequence length is
+always 1 inside a call).  Here the memory lives on the GPU and the gate kernels read and
+overwrite its rows in place; parameters are held by a torch.nn.GRU/LSTM/RNN module so
+names, shapes and initialisation match the reference's state dict, but the step itself is
+computed by libspmi (library GEMMs + fused gate kernels).
+"""
+from __future__ import annotations
+
+import copy
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from spiral_amd import ops
+from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import SimpleDecoder
+
+
+def _is_identity(ids, n: int) -> bool:
+    """True when ids is arange(n).  Tagged tensors (dispatcher output) and CPU tensors are
+    decided without touching the GPU; an untagged GPU tensor is treated as a general
+    index list rather than synchronising to inspect it."""
+    if ids is None or getattr(ids, "_spmi_identity", False):
+        return ids is None or ids.numel() == n
+    if isinstance(ids, torch.Tensor) and ids.device.type == "cpu":
+        return ids.numel() == n and bool(torch.equal(ids, torch.arange(n, dtype=ids.dtype)))
+    return False
+
+
+class NodeMemory:
+    """(n_layers, n_nodes, hidden_d) table of hidden states, one row per node."""
+
+    def __init__(self, n_nodes: int, hidden_d: int, n_layers: int, device=None):
+        self.n_nodes, self.hidden_d, self.n_layers = n_nodes, hidden_d, n_layers
+        self._device = torch.device(device) if device is not None else torch.device("cpu")
+        self.reset_state()
+
+    def reset_state(self):
+        """Fresh standard-normal state, drawn on the CPU generator like the reference
+        (implicitTimeModels.py:46) so that a seeded run yields the same values."""
+        self.memory = torch.randn(self.n_layers, self.n_nodes, self.hidden_d).to(self._device)
+
+    def update_memory(self, new_memory: torch.Tensor, inx):
+        self.memory[:, inx, :] = new_memory.to(self.memory.device)
+
+    def get_memory(self, inx) -> torch.Tensor:
+        return self.memory[:, inx, :]
+
+    @property
+    def device(self):
+        return self.memory.device
+
+    def to(self, device, **kwargs):
+        device = torch.device(device) if device is not None else None
+        if device is None or self.device == device:
+            return self
+        ret = copy.copy(self)
+        ret._device = device
+        ret.memory = self.memory.to(device, **kwargs)
+        return ret
+
+
+class SequentialDecoder(nn.Module):
+    """Gathers embeddings and state by ids, runs one recurrent step, writes the detached
+    state back (only in training mode), then applies the simple decoder."""
+
+    _cell_kind = ""
+
+    def __init__(self, hidden_d: int, n_nodes: int, n_layers: int, simple_decoder: SimpleDecoder):
+        super().__init__()
+        self.n_nodes = n_nodes
+        self.hidden_d = hidden_d
+        self.n_layers = n_layers
+        self.mini_batch = False
+        self.simple_decoder = simple_decoder
+        self.memory_h = NodeMemory(n_nodes, hidden_d, n_layers)
+        self.training_mode = True
+        self.base_model = None
+
+    def set_mini_batch(self, mini_batch: bool = True):
+        self.mini_batch = mini_batch
+
+    @property
+    def device(self):
+        return next(self.base_model.parameters()).device
+
+    def _memories(self) -> List[str]:
+        return ["memory_h"]
+
+    def to(self, device=None, **kwargs):
+        """Moves parameters and node memories; returns self (torch.nn.Module semantics)."""
+        super().to(device, **kwargs)
+        for name in self._memories():
+            setattr(self, name, getattr(self, name).to(device))
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda" if device is None else device))
+
+    def training(self):  # noqa: D401  (reference name; shadows nn.Module.training on purpose)
+        self.training_mode = True
+
+    def eval_mode(self):
+        self.training_mode = False
+
+    def reset_memory_state(self):
+        for name in self._memories():
+            getattr(self, name).reset_state()
+
+    def _check_base_model(self):
+        bm = self.base_model
+        if bm.bidirectional or getattr(bm, "proj_size", 0):
+            raise NotImplementedError("bidirectional / projected recurrent layers are not supported")
+
+    def _layer_params(self, k: int):
+        bm = self.base_model
+        w_ih, w_hh = getattr(bm, f"weight_ih_l{k}"), getattr(bm, f"weight_hh_l{k}")
+        b_ih = getattr(bm, f"bias_ih_l{k}") if bm.bias else None
+        b_hh = getattr(bm, f"bias_hh_l{k}") if bm.bias else None
+        return w_ih, w_hh, b_ih, b_hh
+
+    def _step(self, x: torch.Tensor, ids: Optional[torch.Tensor]) -> torch.Tensor:
+        raise NotImplementedError
+
+    def forward(self, in_state: Tuple[torch.Tensor, List[int]]):
+        node_embs, ids = in_state
+        ids_t = None
+        if not _is_identity(ids, node_embs.shape[0]) or node_embs.shape[0] > self.n_nodes:
+            ids_t = torch.as_tensor(ids, dtype=torch.int64, device=node_embs.device)
+            if not self.mini_batch:
+                node_embs = node_embs[ids_t]
+        for name in self._memories():
+            mem = getattr(self, name)
+            if mem.device != node_embs.device:
+                setattr(self, name, mem.to(node_embs.device))
+        out = self._step(node_embs.reshape(-1, self.input_d), ids_t)
+        return self.simple_decoder((out.view(-1, self.hidden_d), ids))
+
+    def _between_layers(self, x: torch.Tensor, k: int) -> torch.Tensor:
+        bm = self.base_model
+        if bm.dropout > 0 and bm.training and k < self.n_layers - 1:
+            x = F.dropout(x, bm.dropout, training=True)
+        return x
+
+
+class GRU(SequentialDecoder):
+    _cell_kind = "gru"
+
+    def __init__(self, input_d: int, hidden_d: int, n_nodes: int, n_layers: int,
+                 simple_decoder: SimpleDecoder, **kwargs):
+        super().__init__(hidden_d, n_nodes, n_layers, simple_decoder)
+        self.input_d = input_d
+        self.base_model = nn.GRU(input_size=input_d, hidden_size=hidden_d, batch_first=True,
+                                 num_layers=n_layers, **kwargs)
+        self._check_base_model()
+
+    def _step(self, x, ids):
+        for k in range(self.n_layers):
+            x = ops.gru_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,
+                             mem_write=self.training_mode)
+            x = self._between_layers(x, k)
+        return x
+
+
+class RNN(SequentialDecoder):
+    _cell_kind = "rnn"
+
+    def __init__(self, input_d: int, hidden_d: int, n_nodes: int, n_layers: int,
+                 simple_decoder: SimpleDecoder, **kwargs):
+        super().__init__(hidden_d, n_nodes, n_layers, simple_decoder)
+        self.input_d = input_d
+        if kwargs.get("nonlinearity", "tanh") != "tanh":
+            raise NotImplementedError("only the tanh RNN cell is supported")
+        self.base_model = nn.RNN(input_size=input_d, hidden_size=hidden_d, batch_first=True,
+                                 num_layers=n_layers, **kwargs)
+        self._check_base_model()
+
+    def _step(self, x, ids):
+        for k in range(self.n_layers):
+            x = ops.rnn_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,
+                             mem_write=self.training_mode)
+            x = self._between_layers(x, k)
+        return x
+
+
+class LSTM(SequentialDecoder):
+    _cell_kind = "lstm"
+
+    def __init__(self, input_d: int, hidden_d: int, n_nodes: int, n_layers: int,
+                 simple_decoder: SimpleDecoder, **kwargs):
+        super().__init__(hidden_d, n_nodes, n_layers, simple_decoder)
+        self.input_d = input_d
+        self.base_model = nn.LSTM(input_size=input_d, hidden_size=hidden_d, batch_first=True,
+                                  num_layers=n_layers, **kwargs).float()
+        self._check_base_model()
+        self.memory_c = NodeMemory(n_nodes, hidden_d, n_layers)
+
+    def _memories(self) -> List[str]:
+        return ["memory_h", "memory_c"]
+
+    def _step(self, x, ids):
+        for k in range(self.n_layers):
+            x, _c = ops.lstm_cell(x, *self._layer_params(k), self.memory_h.memory[k],
+                                  self.memory_c.memory[k], ids, mem_write=self.training_mode)
+            x = self._between_layers(x, k)
+        return x

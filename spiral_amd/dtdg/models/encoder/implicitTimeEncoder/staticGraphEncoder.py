@@ -1,0 +1,60 @@
+"""Static graph encoders applied to one snapshot at a time; API of
+spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:35-117.
+
+GCN is the encoder on the accelerated path.  SGCN / GAT / GraphSage of the reference
+sit on other DGL layers and are not provided yet.
+"""
+from abc import abstractmethod
+from typing import List, Tuple
+
+import torch.nn.functional as F
+
+from spiral_amd.core.types import GraphConv, MLBaseModel, Tensor, nt_layers_list
+from spiral_amd.dtdg.types import Snapshot
+
+
+class StaticGraphEncoder(MLBaseModel):
+    """Contract of every encoder: `layers` holds the stacked layers, `mini_batch` selects
+    the forward variant, forward((snapshot, ids), training) -> (embeddings, ids)."""
+
+    def __init__(self):
+        super().__init__()
+        self.layers = nt_layers_list()
+        self.mini_batch = False
+
+    @abstractmethod
+    def forward(self, in_sample: Tuple[Snapshot, List], training=False) -> Tuple[Tensor, List]:
+        ...
+
+    def call(self, in_sample: Tuple[Snapshot, List], training=False) -> Tuple[Tensor, List]:
+        return self.forward(in_sample, training)
+
+    def has_weights(self) -> bool:
+        return True
+
+
+class GCN(StaticGraphEncoder):
+    """n_layers GraphConv layers, dropout between them (staticGraphEncoder.py:77-117).
+
+    `dropout` acts only when forward is called with training=True; the reference passes
+    that flag to the dropout layer (staticGraphEncoder.py:115), a Keras-style call that
+    torch.nn.Dropout does not accept, so its intent is reproduced with F.dropout.
+    """
+
+    def __init__(self, n_layers: int, in_feats: int, n_hidden: int, dropout: float = 0, **kwargs):
+        super().__init__()
+        self.n_layers = n_layers
+        self.layers.append(GraphConv(in_feats, n_hidden, **kwargs))
+        for _ in range(n_layers - 1):
+            self.layers.append(GraphConv(n_hidden, n_hidden, **kwargs))
+        self.dropout_p = float(dropout)
+
+    def forward(self, in_sample: Tuple[Snapshot, List], training=False) -> Tuple[Tensor, List]:
+        snapshot, dst_node_ids = in_sample
+        g = snapshot.observation
+        h = self.layers[0](g, snapshot.node_feature())
+        for layer in self.layers[1:]:
+            if training and self.dropout_p > 0:
+                h = F.dropout(h, self.dropout_p, training=True)
+            h = layer(g, h)
+        return (h, dst_node_ids)

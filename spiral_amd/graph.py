@@ -1,0 +1,278 @@
+"""Device-resident snapshot graph: the object that stands where the reference holds a
+`dgl.DGLGraph` (`Snapshot.observation`, spiro/dtdg/types.py:57-59,191).
+
+It keeps the COO edge list the reference builds (`dgl.graph((src, dst), num_nodes)`) and
+materialises, lazily and once per snapshot, what DGL materialises inside libdgl:
+
+* the by-destination CSR (forward aggregation) and the by-source CSR (backward), each a
+  stable grouping with `eid` = original edge position;
+* in/out degrees (row-pointer differences, no atomics) and the GraphConv normalisers;
+* the load-balance plan of the aggregation kernel (hub rows cut into chunks).
+
+Only the DGLGraph methods the reference's torch path touches are provided
+(spiro/dtdg/types.py:67-106,191,241,247; tests/dtdg/test_types_torch.py:49-50).
+All compute runs in libspmi on the GPU; a graph held on the CPU is a plain container
+and raises when asked to compute.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _native as nv
+
+HEAVY_THRESH = 512  # rows with more nonzeros than this are summed chunk-wise by whole workgroups
+HEAVY_CHUNK = 256   # nonzeros per chunk (one workgroup, four waves of 64)
+
+_ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
+
+
+def _i64(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int64 else t.to(torch.int64)
+
+
+@dataclass
+class CSR:
+    """One grouping of a snapshot's edges on the device (int32, see include/spmi.h)."""
+
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    eid: torch.Tensor
+    n_rows: int
+    n_cols: int
+    nnz: int
+    heavy_rows: Optional[torch.Tensor] = None
+    heavy_chunk_ptr: Optional[torch.Tensor] = None
+    n_heavy: int = 0
+    n_chunks: int = 0
+    heavy_thresh: int = HEAVY_THRESH
+    chunk: int = HEAVY_CHUNK
+    _partial: Dict[int, torch.Tensor] = field(default_factory=dict)
+
+    def partial_ws(self, feat: int) -> Optional[torch.Tensor]:
+        if self.n_heavy == 0:
+            return None
+        ws = self._partial.get(feat)
+        if ws is None:
+            ws = torch.empty(self.n_chunks * feat, dtype=torch.float32, device=self.indptr.device)
+            self._partial = {feat: ws}  # keep one size: layers of a model share F
+        return ws
+
+    def degrees(self) -> torch.Tensor:
+        """int64 row degrees, like DGLGraph.in_degrees()."""
+        return (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
+
+    def norm(self, mode: int) -> torch.Tensor:
+        out = torch.empty(self.n_rows, dtype=torch.float32, device=self.indptr.device)
+        nv.check(nv.lib().spmi_norm_from_indptr(nv.ptr(self.indptr), self.n_rows, mode,
+                                                nv.ptr(out), nv.stream()), "spmi_norm_from_indptr")
+        return out
+
+
+def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
+              heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK) -> CSR:
+    """COO -> CSR grouped by `key` plus the aggregation plan (one host sync to read the
+    status word and the plan sizes)."""
+    nv.require_cuda(key, other)
+    key, other = _i64(key).contiguous(), _i64(other).contiguous()
+    dev = key.device
+    e = key.numel()
+    lib = nv.lib()
+    with torch.cuda.device(dev):
+        indptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
+        indices = torch.empty(e, dtype=torch.int32, device=dev)
+        eid = torch.empty(e, dtype=torch.int32, device=dev)
+        meta = torch.zeros(3, dtype=torch.int32, device=dev)  # status, n_heavy, n_chunks
+        ws_bytes = lib.spmi_coo_to_csr_workspace_bytes(e, n_key)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        nv.check(lib.spmi_coo_to_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
+                                     nv.ptr(indices), nv.ptr(eid), nv.ptr(ws), ws_bytes,
+                                     nv.ptr(meta), nv.stream()), "spmi_coo_to_csr")
+        cap = e // heavy_thresh + 2
+        heavy_rows = torch.empty(cap, dtype=torch.int32, device=dev)
+        heavy_ptr = torch.empty(cap, dtype=torch.int32, device=dev)
+        nv.check(lib.spmi_spmm_plan(nv.ptr(indptr), n_key, heavy_thresh, chunk, nv.ptr(heavy_rows),
+                                    nv.ptr(heavy_ptr), cap, nv.ptr(meta[1:]), nv.stream()),
+                 "spmi_spmm_plan")
+        status, n_heavy, n_chunks = meta.tolist()
+    if status != 0:
+        raise nv.SpmiError(f"edge list holds a node id outside [0, {n_key}) / [0, {n_other})")
+    return CSR(indptr, indices, eid, n_key, n_other, e, heavy_rows, heavy_ptr, n_heavy, n_chunks,
+               heavy_thresh, chunk)
+
+
+def degree(ids: torch.Tensor, n: int) -> torch.Tensor:
+    """deg[v] = occurrences of v in ids (int64), by keys-only sort + run boundaries."""
+    nv.require_cuda(ids)
+    ids = _i64(ids).contiguous()
+    dev = ids.device
+    lib = nv.lib()
+    with torch.cuda.device(dev):
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.spmi_degree_workspace_bytes(ids.numel(), n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        nv.check(lib.spmi_degree(nv.ptr(ids), ids.numel(), n, nv.ptr(out), nv.ptr(ws), ws_bytes,
+                                 nv.ptr(status), nv.stream()), "spmi_degree")
+        if status.item() != 0:
+            raise nv.SpmiError(f"node id outside [0, {n})")
+    return out
+
+
+def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = None,
+              edge_w: Optional[torch.Tensor] = None, dst_scale: Optional[torch.Tensor] = None,
+              bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+              slope: float = 0.01, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y = act(dst_scale * (A (src_scale * X) with edge weights) + bias), one fused launch
+    (plus two for hub rows).  No autograd here; see ops.GcnAggregate."""
+    nv.require_cuda(x, src_scale, edge_w, dst_scale, bias, out)
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise nv.SpmiError(f"aggregate expects a 2-D float32 feature matrix, got {tuple(x.shape)} "
+                           f"{x.dtype}")
+    if x.shape[0] != csr.n_cols:
+        raise nv.SpmiError(f"feature matrix has {x.shape[0]} rows, the graph addresses {csr.n_cols}")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    feat = x.shape[1]
+    for name, t, n in (("src_scale", src_scale, csr.n_cols), ("edge_w", edge_w, csr.nnz),
+                       ("dst_scale", dst_scale, csr.n_rows), ("bias", bias, feat)):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous()):
+            raise nv.SpmiError(f"{name} must be contiguous float32 with {n} elements")
+    if out is None:
+        out = torch.empty(csr.n_rows, feat, dtype=torch.float32, device=x.device)
+    elif out.shape != (csr.n_rows, feat) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise nv.SpmiError("bad `out` tensor")
+    with torch.cuda.device(x.device):
+        partial = csr.partial_ws(feat)
+        nv.check(nv.lib().spmi_gcn_spmm(
+            nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.n_cols, csr.nnz,
+            nv.ptr(x), x.stride(0), feat, nv.ptr(src_scale), nv.ptr(edge_w), nv.ptr(dst_scale),
+            nv.ptr(bias), _ACT_CODES[act], float(slope), nv.ptr(out), out.stride(0),
+            nv.ptr(csr.heavy_rows), nv.ptr(csr.heavy_chunk_ptr), csr.n_heavy, csr.n_chunks,
+            csr.heavy_thresh, csr.chunk, nv.ptr(partial), nv.stream()), "spmi_gcn_spmm")
+    return out
+
+
+class _FrameDict(dict):
+    """ndata / edata: feature name -> tensor, checked against the number of rows."""
+
+    def __init__(self, rows: int, what: str):
+        super().__init__()
+        self._rows, self._what = rows, what
+
+    def __setitem__(self, key, value):
+        if value.shape[0] != self._rows:
+            raise ValueError(f"Expect number of features to match number of {self._what} "
+                             f"(len(u)). Got {value.shape[0]} and {self._rows} instead.")
+        super().__setitem__(key, value)
+
+
+class SnapshotGraph:
+    """Stand-in for the `dgl.DGLGraph` of one snapshot (homogeneous, directed, multi-edges
+    and self-loops kept, edge ids = positions in the COO list)."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: Optional[int] = None):
+        src, dst = torch.as_tensor(src), torch.as_tensor(dst)
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src and dst must be 1-D tensors of equal length")
+        if src.device != dst.device:
+            raise ValueError("src and dst must live on the same device")
+        self._src, self._dst = _i64(src), _i64(dst)
+        if num_nodes is None:
+            num_nodes = int(max(src.max().item(), dst.max().item())) + 1 if src.numel() else 0
+        self._n = int(num_nodes)
+        self.ndata = _FrameDict(self._n, "nodes")
+        self.edata = _FrameDict(src.numel(), "edges")
+        self._csr: Optional[CSR] = None      # grouped by destination
+        self._csr_t: Optional[CSR] = None    # grouped by source
+        self._out_deg: Optional[torch.Tensor] = None
+        self._norms: Dict[Tuple[str, int], torch.Tensor] = {}
+
+    # ---- DGLGraph surface used by the reference -----------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self._src.device
+
+    def num_nodes(self) -> int:
+        return self._n
+
+    def number_of_nodes(self) -> int:
+        return self._n
+
+    def num_edges(self) -> int:
+        return self._src.numel()
+
+    def number_of_edges(self) -> int:
+        return self._src.numel()
+
+    def edges(self):
+        return self._src, self._dst
+
+    def to(self, device, **kwargs) -> "SnapshotGraph":
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        g = SnapshotGraph(self._src.to(device, **kwargs), self._dst.to(device, **kwargs), self._n)
+        for k, v in self.ndata.items():
+            g.ndata[k] = v.to(device, **kwargs)
+        for k, v in self.edata.items():
+            g.edata[k] = v.to(device, **kwargs)
+        return g
+
+    def in_degrees(self) -> torch.Tensor:
+        return self.csr().degrees()
+
+    def out_degrees(self) -> torch.Tensor:
+        if self._csr_t is not None:
+            return self._csr_t.degrees()
+        if self._out_deg is None:
+            self._out_deg = degree(self._src, self._n)
+        return self._out_deg
+
+    def add_self_loop(self) -> "SnapshotGraph":
+        """dgl.add_self_loop: append (v, v) for every node after the existing edges; node
+        features are kept, edge features of the new edges are zero-filled."""
+        loops = torch.arange(self._n, dtype=torch.int64, device=self.device)
+        g = SnapshotGraph(torch.cat([self._src, loops]), torch.cat([self._dst, loops]), self._n)
+        for k, v in self.ndata.items():
+            g.ndata[k] = v
+        for k, v in self.edata.items():
+            pad = torch.zeros((self._n,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            g.edata[k] = torch.cat([v, pad])
+        return g
+
+    # ---- device structures ------------------------------------------------------------
+    def csr(self) -> CSR:
+        if self._csr is None:
+            self._csr = build_csr(self._dst, self._src, self._n, self._n)
+        return self._csr
+
+    def csr_t(self) -> CSR:
+        if self._csr_t is None:
+            self._csr_t = build_csr(self._src, self._dst, self._n, self._n)
+        return self._csr_t
+
+    def norm(self, side: str, mode: int) -> torch.Tensor:
+        """GraphConv normaliser: side 'in' (destination, in-degree) or 'out' (source,
+        out-degree); mode 0 = clamp(deg,1)^-0.5, 1 = 1/clamp(deg,1)."""
+        key = (side, mode)
+        if key not in self._norms:
+            if side == "in":
+                self._norms[key] = self.csr().norm(mode)
+            elif self._csr_t is not None or torch.is_grad_enabled():
+                self._norms[key] = self.csr_t().norm(mode)
+            else:
+                degs = self.out_degrees().to(torch.float32).clamp_(min=1)
+                self._norms[key] = degs.sqrt_().reciprocal_() if mode == 0 else degs.reciprocal_()
+        return self._norms[key]
+
+
+def graph(data, num_nodes: Optional[int] = None, device=None) -> SnapshotGraph:
+    """`dgl.graph((src, dst), num_nodes=...)` as the reference calls it (types.py:191)."""
+    src, dst = data
+    src, dst = torch.as_tensor(src), torch.as_tensor(dst)
+    if device is not None:
+        src, dst = src.to(device), dst.to(device)
+    return SnapshotGraph(src, dst, num_nodes)

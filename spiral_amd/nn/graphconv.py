@@ -1,0 +1,112 @@
+"""GraphConv with the constructor, parameters and forward signature of
+dgl.nn.pytorch.conv.GraphConv (DGL 0.8), which the reference imports at
+spiro/core/types.py:34 and calls at staticGraphEncoder.py:93,96,113,116.
+
+    h = act( D_in^-1/2 A (D_out^-1/2 X) W + b )          (norm='both')
+
+X W runs first iff in_feats > out_feats, as in DGL.  The degree scalings, the sparse
+sum, the bias and (relu / leaky_relu) activation are one fused libspmi launch; the dense
+product is a plain library GEMM.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from spiral_amd.core.errors import GraphError
+from spiral_amd.graph import SnapshotGraph
+from spiral_amd.ops import gcn_aggregate
+
+
+def _classify_activation(act) -> Tuple[Optional[str], float, Optional[Callable]]:
+    """(fused code, slope, unfused callable)."""
+    if act is None:
+        return None, 0.01, None
+    if act in (F.relu, torch.relu) or isinstance(act, nn.ReLU):
+        return "relu", 0.0, None
+    if act is F.leaky_relu:
+        return "leaky_relu", 0.01, None
+    if isinstance(act, nn.LeakyReLU):
+        return "leaky_relu", float(act.negative_slope), None
+    return None, 0.01, act
+
+
+class GraphConv(nn.Module):
+    def __init__(self, in_feats: int, out_feats: int, norm: str = "both", weight: bool = True,
+                 bias: bool = True, activation=None, allow_zero_in_degree: bool = False):
+        super().__init__()
+        if norm not in ("none", "both", "right", "left"):
+            raise GraphError(
+                f'Invalid norm value. Must be either "none", "both", "right" or "left". But got "{norm}".')
+        self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
+        self._allow_zero_in_degree = allow_zero_in_degree
+        if weight:
+            self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        else:
+            self.register_parameter("weight", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_feats))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self._activation = activation
+
+    def reset_parameters(self) -> None:
+        """Glorot-uniform weight, zero bias (DGL GraphConv.reset_parameters)."""
+        if self.weight is not None:
+            nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def set_allow_zero_in_degree(self, set_value: bool) -> None:
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph: SnapshotGraph, feat: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not isinstance(graph, SnapshotGraph):
+            raise GraphError(f"expected a spiral_amd SnapshotGraph, got {type(graph).__name__}")
+        if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+            raise GraphError(
+                "There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                "Adding self-loop on the input graph by calling `g = g.add_self_loop()` will resolve "
+                "the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing this "
+                "module will suppress the check and let the code run.")
+        if weight is not None:
+            if self.weight is not None:
+                raise GraphError("External weight is provided while at the same time the module has "
+                                 "defined its own weight parameter. Please create the module with "
+                                 "flag weight=False.")
+        else:
+            weight = self.weight
+
+        mode = 0 if self._norm == "both" else 1
+        src_scale = graph.norm("out", mode) if self._norm in ("left", "both") else None
+        dst_scale = graph.norm("in", mode) if self._norm in ("right", "both") else None
+        code, slope, unfused = _classify_activation(self._activation)
+
+        if self._in_feats > self._out_feats:
+            if weight is not None:
+                feat = feat @ weight
+            rst = gcn_aggregate(graph, feat, src_scale, dst_scale, self.bias, edge_weight, code, slope)
+        else:
+            rst = gcn_aggregate(graph, feat, src_scale, dst_scale, None, edge_weight, None)
+            if weight is not None:
+                rst = torch.addmm(self.bias, rst, weight) if self.bias is not None else rst @ weight
+            elif self.bias is not None:
+                rst = rst + self.bias
+            if code == "relu":
+                rst = F.relu(rst)
+            elif code == "leaky_relu":
+                rst = F.leaky_relu(rst, slope)
+        if unfused is not None:
+            rst = unfused(rst)
+        return rst
+
+    def extra_repr(self) -> str:
+        s = f"in={self._in_feats}, out={self._out_feats}, normalization={self._norm}"
+        if self._activation is not None:
+            s += f", activation={self._activation}"
+        return s

@@ -1,0 +1,236 @@
+"""Autograd wrappers over the libspmi kernels (include/spmi.h).
+
+`gcn_aggregate` is the fused normalised aggregation of GraphConv.forward (DGL, called at
+spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:113,116); the
+`*_cell` functions are one step of torch.nn.GRU/LSTM/RNN over all nodes, fused with the
+NodeMemory read/write of implicitTimeModels.py:48-54,153-156.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nv
+from .graph import SnapshotGraph, aggregate
+
+
+def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope: float,
+                  want_gb: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """gP = gY * act'(Y) and gb = column sums of gP, one pass."""
+    m, f = g_y.shape
+    if g_y.stride(1) != 1 or g_y.stride(0) != y.stride(0):
+        g_y = g_y.contiguous()
+        y = y.contiguous()
+    g_p = torch.empty(m, f, dtype=torch.float32, device=g_y.device)
+    g_b = torch.zeros(f, dtype=torch.float32, device=g_y.device) if want_gb else None
+    code = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}[act]
+    with torch.cuda.device(g_y.device):
+        nv.check(nv.lib().spmi_act_bias_bwd(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code,
+                                            float(slope), nv.ptr(g_p), nv.ptr(g_b), nv.stream()),
+                 "spmi_act_bias_bwd")
+    return g_p, g_b
+
+
+class GcnAggregate(torch.autograd.Function):
+    """Y = act(norm_dst * A (norm_src * X) + bias) with A the snapshot's adjacency
+    (rows = destinations).  Backward runs the same kernel on the by-source CSR with the
+    two normalisers exchanged: dX = norm_src * A^T (norm_dst * dP)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, g: SnapshotGraph, src_scale, dst_scale, edge_weight, act, slope):
+        csr = g.csr()
+        ew = None if edge_weight is None else edge_weight.detach()[csr.eid.long()].contiguous()
+        y = aggregate(csr, x.detach(), src_scale, ew, dst_scale,
+                      None if bias is None else bias.detach(), act, slope)
+        ctx.g, ctx.src_scale, ctx.dst_scale = g, src_scale, dst_scale
+        ctx.edge_weight, ctx.act, ctx.slope = edge_weight, act, slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        (y,) = ctx.saved_tensors
+        need_x, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_bias
+        g_p, g_b = g_y, None
+        if y is not None or need_b:
+            g_p, g_b = _act_bias_bwd(g_y, y if y is not None else g_y, ctx.act, ctx.slope, need_b)
+        g_x = None
+        if need_x:
+            csr_t = ctx.g.csr_t()
+            ew = None
+            if ctx.edge_weight is not None:
+                ew = ctx.edge_weight.detach()[csr_t.eid.long()].contiguous()
+            g_x = aggregate(csr_t, g_p, ctx.dst_scale, ew, ctx.src_scale, None, None)
+        return g_x, g_b, None, None, None, None, None, None
+
+
+def gcn_aggregate(g: SnapshotGraph, x: torch.Tensor, src_scale: Optional[torch.Tensor] = None,
+                  dst_scale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                  edge_weight: Optional[torch.Tensor] = None, act: Optional[str] = None,
+                  slope: float = 0.01) -> torch.Tensor:
+    if edge_weight is not None and edge_weight.requires_grad:
+        raise nv.SpmiError("gradients with respect to edge_weight are not implemented")
+    return GcnAggregate.apply(x, bias, g, src_scale, dst_scale, edge_weight, act, slope)
+
+
+# --------------------------------------------------------------------------- recurrent cells
+def _rows(mem: torch.Tensor, ids: Optional[torch.Tensor], m: int) -> torch.Tensor:
+    """Dense [M,H] view/copy of the memory rows a batch reads (GEMM operand)."""
+    if ids is None:
+        return mem[:m]
+    out = torch.empty(m, mem.shape[1], dtype=torch.float32, device=mem.device)
+    with torch.cuda.device(mem.device):
+        nv.check(nv.lib().spmi_gather_rows(nv.ptr(mem), mem.stride(0), nv.ptr(ids), m,
+                                           mem.shape[1], nv.ptr(out), nv.stream()),
+                 "spmi_gather_rows")
+    return out
+
+
+def _check_cell_args(x, mem, ids):
+    nv.require_cuda(x, mem, ids)
+    if x.dtype != torch.float32 or mem.dtype != torch.float32:
+        raise nv.SpmiError("recurrent cells compute in float32")
+    if not mem.is_contiguous():
+        raise nv.SpmiError("node memory layer must be contiguous")
+    if ids is not None and (ids.dtype != torch.int64 or ids.numel() != x.shape[0]):
+        raise nv.SpmiError("ids must be int64 with one entry per batch row")
+    if ids is None and x.shape[0] > mem.shape[0]:
+        raise nv.SpmiError("batch larger than the node memory")
+
+
+class GruCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        h_old = _rows(h_mem, ids, m)
+        gi = xd @ w_ih.detach().t()
+        gh = h_old @ w_hh.detach().t()
+        need_grad = any(ctx.needs_input_grad[:5])
+        saved = torch.empty(m, 5 * hd, dtype=torch.float32, device=x.device) if need_grad else None
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nv.check(nv.lib().spmi_gru_gate_fwd(
+                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
+                hd, nv.ptr(h_out), int(mem_write), nv.ptr(saved), nv.stream()), "spmi_gru_gate_fwd")
+        ctx.save_for_backward(xd, w_ih, w_hh, saved)
+        ctx.has_bias = b_ih is not None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, g_h):
+        xd, w_ih, w_hh, saved = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g_gi = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_h.device)
+        g_gh = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_gru_gate_bwd(nv.ptr(g_h), nv.ptr(saved), m, hd, nv.ptr(g_gi),
+                                                nv.ptr(g_gh), None, nv.stream()),
+                     "spmi_gru_gate_bwd")
+        h_old = saved[:, 4 * hd:]
+        g_x = g_gi @ w_ih if ctx.needs_input_grad[0] else None
+        g_wih = g_gi.t() @ xd if ctx.needs_input_grad[1] else None
+        g_whh = g_gh.t() @ h_old if ctx.needs_input_grad[2] else None
+        g_bih = g_gi.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        g_bhh = g_gh.sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
+
+
+class LstmCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        h_old = _rows(h_mem, ids, m)
+        need_grad = any(ctx.needs_input_grad[:5])
+        if need_grad and mem_write and ids is None:
+            h_old = h_old.clone()  # the backward needs h_old after the memory rows are overwritten
+        gi = xd @ w_ih.detach().t()
+        gh = h_old @ w_hh.detach().t()
+        saved = torch.empty(m, 6 * hd, dtype=torch.float32, device=x.device) if need_grad else None
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        c_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nv.check(nv.lib().spmi_lstm_gate_fwd(
+                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem),
+                nv.ptr(ids), m, hd, nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
+                nv.stream()), "spmi_lstm_gate_fwd")
+        ctx.save_for_backward(xd, w_ih, w_hh, saved, h_old if need_grad else None)
+        ctx.has_bias = b_ih is not None
+        ctx.mark_non_differentiable(c_out)
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, g_h, _g_c):
+        xd, w_ih, w_hh, saved, h_old = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g_g = torch.empty(m, 4 * hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_lstm_gate_bwd(nv.ptr(g_h), None, nv.ptr(saved), m, hd,
+                                                 nv.ptr(g_g), None, nv.stream()),
+                     "spmi_lstm_gate_bwd")
+        g_x = g_g @ w_ih if ctx.needs_input_grad[0] else None
+        g_wih = g_g.t() @ xd if ctx.needs_input_grad[1] else None
+        g_whh = g_g.t() @ h_old if ctx.needs_input_grad[2] else None
+        g_b = g_g.sum(0) if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        return g_x, g_wih, g_whh, g_b, g_b, None, None, None, None
+
+
+class RnnCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        h_old = _rows(h_mem, ids, m)
+        need_grad = any(ctx.needs_input_grad[:5])
+        if need_grad and mem_write and ids is None:
+            h_old = h_old.clone()
+        gi = xd @ w_ih.detach().t()
+        gh = h_old @ w_hh.detach().t()
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nv.check(nv.lib().spmi_rnn_gate_fwd(
+                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
+                hd, nv.ptr(h_out), int(mem_write), nv.stream()), "spmi_rnn_gate_fwd")
+        ctx.save_for_backward(xd, w_ih, w_hh, h_out, h_old if need_grad else None)
+        ctx.has_bias = b_ih is not None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, g_h):
+        xd, w_ih, w_hh, h_out, h_old = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g_g = torch.empty(m, hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_rnn_gate_bwd(nv.ptr(g_h), nv.ptr(h_out), m, hd, nv.ptr(g_g),
+                                                nv.stream()), "spmi_rnn_gate_bwd")
+        g_x = g_g @ w_ih if ctx.needs_input_grad[0] else None
+        g_wih = g_g.t() @ xd if ctx.needs_input_grad[1] else None
+        g_whh = g_g.t() @ h_old if ctx.needs_input_grad[2] else None
+        g_b = g_g.sum(0) if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
+        return g_x, g_wih, g_whh, g_b, g_b, None, None, None
+
+
+def gru_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
+    """One GRU step for a batch of nodes.  h_mem is one layer of the node memory
+    ([n_nodes, H], read at rows `ids`, overwritten there with the detached new state when
+    mem_write).  Returns the new hidden state [M, H] (differentiable w.r.t. x and weights;
+    the memory is a constant, as in the reference where it never carries a graph)."""
+    _check_cell_args(x, h_mem, ids)
+    return GruCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write)
+
+
+def lstm_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids=None, mem_write=True):
+    _check_cell_args(x, h_mem, ids)
+    _check_cell_args(x, c_mem, ids)
+    return LstmCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write)
+
+
+def rnn_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
+    _check_cell_args(x, h_mem, ids)
+    return RnnCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write)

@@ -1,0 +1,96 @@
+"""GPU parity of the integer half of the path: degrees and COO -> CSR must be bit-exact
+against the CPU oracle (stable grouping, eid = original position)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from spiral_amd import _native as nv
+from spiral_amd import graph as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_csr(src, dst, n, dev):
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+    indptr, indices, eid = orc.coo_to_csr(dst, src, n)
+    assert np.array_equal(csr.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(csr.indices.cpu().numpy(), indices)
+    assert np.array_equal(csr.eid.cpu().numpy(), eid)
+    return csr
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 5, 0), (2, 1, 1), (7, 64, 2), (300, 4095, 3), (300, 4096, 4),
+                                      (300, 4097, 5), (1000, 8000, 6), (70000, 200000, 7),
+                                      (20_000_000, 300000, 8)])
+def test_coo_to_csr_random(dev, n, e, seed):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e, dtype=np.int64)
+    dst = rng.integers(0, n, e, dtype=np.int64)
+    _check_csr(src, dst, n, dev)
+
+
+def test_coo_to_csr_powerlaw_and_degrees(dev):
+    n, e = 100_000, 1_000_000
+    src, dst = orc.powerlaw_snapshot(n, e, t=0)
+    csr = _check_csr(src, dst, n, dev)
+    assert np.array_equal(csr.degrees().cpu().numpy(), orc.degree(dst, n))
+    out_deg = G.degree(torch.from_numpy(src).to(dev), n)
+    assert out_deg.dtype == torch.int64
+    assert np.array_equal(out_deg.cpu().numpy(), orc.degree(src, n))
+
+
+def test_coo_to_csr_edge_cases(dev):
+    # no edges at all
+    csr = G.build_csr(torch.zeros(0, dtype=torch.int64, device=dev),
+                      torch.zeros(0, dtype=torch.int64, device=dev), 5, 5)
+    assert csr.indptr.cpu().tolist() == [0] * 6
+    # every edge into one node; long runs of empty rows on both sides of it
+    n, e = 50_000, 20_000
+    dst = np.full(e, 31_337, dtype=np.int64)
+    src = np.arange(e, dtype=np.int64) % n
+    _check_csr(src, dst, n, dev)
+    # only the last / only the first node
+    _check_csr(src, np.full(e, n - 1, dtype=np.int64), n, dev)
+    _check_csr(src, np.zeros(e, dtype=np.int64), n, dev)
+    # the reference fixture (tests/dtdg/test_types_torch.py:12): edges [t, src, dst]
+    edges = np.array([[0, 0, 1], [0, 0, 2], [1, 3, 0], [2, 4, 1]])
+    _check_csr(edges[:, 1].astype(np.int64), edges[:, 2].astype(np.int64), 5, dev)
+
+
+def test_out_of_range_id_is_reported(dev):
+    dst = torch.tensor([0, 1, 9], dtype=torch.int64, device=dev)
+    src = torch.tensor([0, 1, 2], dtype=torch.int64, device=dev)
+    with pytest.raises(nv.SpmiError):
+        G.build_csr(dst, src, 5, 5)
+    with pytest.raises(nv.SpmiError):
+        G.build_csr(src, dst, 5, 5)  # bad id on the `other` side
+    with pytest.raises(nv.SpmiError):
+        G.degree(torch.tensor([-1, 2], dtype=torch.int64, device=dev), 5)
+
+
+def test_plan_lists_exactly_the_heavy_rows(dev):
+    n, e = 20_000, 400_000
+    src, dst = orc.powerlaw_snapshot(n, e, t=1, k_dst=6.0)
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n,
+                      heavy_thresh=128, chunk=64)
+    deg = orc.degree(dst, n)
+    want = np.nonzero(deg > 128)[0]
+    got = csr.heavy_rows[: csr.n_heavy].cpu().numpy()
+    assert np.array_equal(np.sort(got), want)
+    ptr = csr.heavy_chunk_ptr[: csr.n_heavy + 1].cpu().numpy()
+    assert ptr[0] == 0 and ptr[-1] == csr.n_chunks
+    assert np.array_equal(np.diff(ptr), (deg[got] + 63) // 64)
+
+
+def test_norm_matches_oracle(dev):
+    n, e = 5000, 40_000
+    src, dst = orc.powerlaw_snapshot(n, e, t=2)
+    g = G.SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    ip_in, _, _ = orc.coo_to_csr(dst, src, n)
+    ip_out, _, _ = orc.coo_to_csr(src, dst, n)
+    for side, ip in (("in", ip_in), ("out", ip_out)):
+        for mode, name in ((0, "rsqrt"), (1, "recip")):
+            with torch.no_grad():
+                got = g.norm(side, mode).cpu().numpy()
+            np.testing.assert_allclose(got, orc.norm_from_indptr(ip, name), rtol=2e-7, atol=0)

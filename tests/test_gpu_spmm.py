@@ -1,0 +1,95 @@
+"""GPU parity of the fused normalised aggregation against the CPU oracle.
+
+Tolerance: |got - want| <= 1e-5 * S elementwise, where S is the same aggregation applied
+to absolute values (sum of |w_j x_j| + |bias|): the fp32 bound that does not blow up when
+signed terms cancel.  The kernel differs from the oracle only by fused multiply-adds and,
+for hub rows, by the (fixed) order of the sum."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from spiral_amd import graph as G
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _close(got, want, scale):
+    err = np.abs(got - want) / np.maximum(scale, 1e-30)
+    assert err.max() <= RTOL, f"max relative error {err.max():.3e}"
+
+
+def _run(dev, n, e, f, seed, k_dst=3.0, scales=True, bias=True, act=None, ew=False,
+         heavy_thresh=G.HEAVY_THRESH, chunk=G.HEAVY_CHUNK, ld_pad=0):
+    rng = np.random.default_rng(seed)
+    src, dst = orc.powerlaw_snapshot(n, e, t=seed, k_dst=k_dst)
+    x = rng.standard_normal((n, f + ld_pad)).astype(np.float32)[:, :f]
+    indptr, indices, eid = orc.coo_to_csr(dst, src, n)
+    ss = orc.norm_from_indptr(orc.coo_to_csr(src, dst, n)[0]) if scales else None
+    ds = orc.norm_from_indptr(indptr) if scales else None
+    b = rng.standard_normal(f).astype(np.float32) if bias else None
+    w = rng.random(e).astype(np.float32)[eid] if ew else None
+    want = orc.aggregate(indptr, indices, x, ss, w, ds, b, act, 0.01)
+    scale = orc.aggregate(indptr, indices, np.abs(x), ss, w, ds, None if b is None else np.abs(b))
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n,
+                      heavy_thresh=heavy_thresh, chunk=chunk)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xd = torch.from_numpy(np.ascontiguousarray(rng.standard_normal((n, f + ld_pad)).astype(np.float32))).to(dev)
+    xd[:, :f] = t(x)
+    got = G.aggregate(csr, xd[:, :f], t(ss), t(w), t(ds), t(b), act, 0.01).cpu().numpy()
+    _close(got, want, scale + 1e-30)
+    return csr
+
+
+@pytest.mark.parametrize("f", [1, 3, 10, 32, 64, 96, 128, 129, 256, 320, 512])
+def test_feature_widths(dev, f):
+    _run(dev, 3000, 30_000, f, seed=f, act="leaky_relu")
+
+
+@pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
+@pytest.mark.parametrize("scales,bias,ew", [(False, False, False), (True, False, False),
+                                            (True, True, False), (True, True, True),
+                                            (False, True, True)])
+def test_epilogue_combinations(dev, act, scales, bias, ew):
+    _run(dev, 2000, 16_000, 128, seed=11, scales=scales, bias=bias, act=act, ew=ew)
+
+
+def test_heavy_rows_take_the_chunked_path(dev):
+    csr = _run(dev, 20_000, 600_000, 128, seed=5, k_dst=6.0, act="relu", heavy_thresh=128, chunk=64)
+    assert csr.n_heavy > 0 and csr.n_chunks > csr.n_heavy
+    csr = _run(dev, 20_000, 600_000, 256, seed=6, k_dst=6.0)
+    assert csr.n_heavy > 0
+    _run(dev, 20_000, 600_000, 10, seed=7, k_dst=6.0, heavy_thresh=100, chunk=100)
+
+
+def test_empty_rows_and_padded_leading_dimension(dev):
+    # mostly empty rows: output must still be act(bias)
+    _run(dev, 50_000, 5_000, 128, seed=3, act="leaky_relu")
+    _run(dev, 4000, 40_000, 128, seed=4, ld_pad=8)
+    _run(dev, 4000, 40_000, 130, seed=4, ld_pad=2)
+
+
+def test_unit_weights_are_bit_exact_for_light_rows(dev):
+    """Without scaling the kernel adds the same fp32 values in the same (CSR) order as the
+    oracle, so rows below the heavy threshold agree bit for bit."""
+    n, e, f = 5000, 50_000, 128
+    rng = np.random.default_rng(0)
+    src, dst = orc.powerlaw_snapshot(n, e, t=9, k_dst=1.0)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    indptr, indices, _ = orc.coo_to_csr(dst, src, n)
+    want = orc.aggregate(indptr, indices, x)
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+    assert csr.n_heavy == 0
+    got = G.aggregate(csr, torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_repeatable(dev):
+    n, e, f = 30_000, 900_000, 128
+    src, dst = orc.powerlaw_snapshot(n, e, t=4, k_dst=6.0)
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+    x = torch.randn(n, f, device=dev)
+    a = G.aggregate(csr, x)
+    b = G.aggregate(csr, x)
+    assert torch.equal(a, b)
