@@ -1,0 +1,165 @@
+"""GraphConv layer and the snapshot container on the GPU against the CPU oracle.
+fp32 tolerance 1e-5 relative (to the largest magnitude of the compared tensor) for
+outputs, loss and gradients."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as orc
+from spiral_amd.core.errors import GraphError
+from spiral_amd.core.types import GraphConv
+from spiral_amd.dtdg.types import CitationGraph
+from spiral_amd.graph import SnapshotGraph
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ACTS = {"leaky_relu": F.leaky_relu, "relu": F.relu, None: None}
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _layer(fi, fo, w, b, dev, **kw):
+    conv = GraphConv(fi, fo, allow_zero_in_degree=True, **kw).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(w))
+        conv.bias.copy_(torch.from_numpy(b))
+    return conv
+
+
+def test_small_graph_goldens_all_norms_both_weight_orders(dev):
+    g = np.load(os.path.join(GOLD, "graphconv.npz"))
+    src, dst, x = g["small/src"], g["small/dst"], g["small/x"]
+    graph = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), 7)
+    assert graph.in_degrees().cpu().tolist() == orc.degree(dst, 7).tolist()
+    assert graph.out_degrees().cpu().tolist() == orc.degree(src, 7).tolist()
+    for fo in (4, 6, 9):  # 6 -> 4 multiplies first, 6 -> 6 and 6 -> 9 aggregate first
+        for norm in ("both", "right", "left", "none"):
+            conv = _layer(6, fo, g[f"small/w{fo}"], g[f"small/b{fo}"], dev, norm=norm,
+                          activation=F.leaky_relu)
+            y = conv(graph, torch.from_numpy(x).to(dev)).detach().cpu().numpy()
+            assert rel(y, g[f"small/y_{norm}_{fo}"]) < 1e-5, (fo, norm)
+
+
+def test_zero_in_degree_raises_unless_allowed(dev):
+    graph = SnapshotGraph(torch.tensor([0, 1], device=dev), torch.tensor([1, 0], device=dev), 3)
+    conv = GraphConv(4, 4).to(dev)
+    with pytest.raises(GraphError):
+        conv(graph, torch.zeros(3, 4, device=dev))
+    conv.set_allow_zero_in_degree(True)
+    assert conv(graph, torch.zeros(3, 4, device=dev)).shape == (3, 4)
+    ext = GraphConv(4, 4, weight=False, allow_zero_in_degree=True).to(dev)
+    w = torch.eye(4, device=dev)
+    assert ext(graph, torch.ones(3, 4, device=dev), weight=w).shape == (3, 4)
+    with pytest.raises(GraphError):
+        conv(graph, torch.zeros(3, 4, device=dev), weight=w)
+
+
+@pytest.mark.parametrize("fi,fo,act", [(16, 8, "relu"), (16, 16, "leaky_relu"), (16, 24, None),
+                                       (128, 128, "leaky_relu"), (129, 32, "leaky_relu")])
+def test_forward_loss_and_gradients_match_the_torch_restatement(dev, fi, fo, act):
+    n, e = 1000, 8000
+    rng = np.random.default_rng(fi * 100 + fo)
+    src, dst = orc.powerlaw_snapshot(n, e, t=fi)
+    x = rng.standard_normal((n, fi)).astype(np.float32)
+    w = (rng.standard_normal((fi, fo)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(fo).astype(np.float32)
+
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    y_ref = orc.graphconv_torch(src, dst, n, xt, wt, bt, act=act)
+    loss_ref = (y_ref ** 2).mean()
+    loss_ref.backward()
+
+    graph = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    conv = _layer(fi, fo, w, b, dev, activation=ACTS[act])
+    xg = torch.tensor(x, device=dev, requires_grad=True)
+    y = conv(graph, xg)
+    loss = (y ** 2).mean()
+    loss.backward()
+
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-5
+    assert rel(xg.grad.cpu(), xt.grad) < 1e-5
+    assert rel(conv.weight.grad.cpu(), wt.grad) < 1e-5
+    assert rel(conv.bias.grad.cpu(), bt.grad) < 1e-5
+
+
+def test_powerlaw_golden_with_gradients(dev):
+    g = np.load(os.path.join(GOLD, "graphconv.npz"))
+    n = 1000
+    graph = SnapshotGraph(torch.from_numpy(g["pl/src"]).to(dev), torch.from_numpy(g["pl/dst"]).to(dev), n)
+    conv = _layer(16, 8, g["pl/w"], g["pl/b"], dev, activation=F.relu)
+    xg = torch.tensor(g["pl/x"], device=dev, requires_grad=True)
+    y = conv(graph, xg)
+    loss = (y ** 2).mean()
+    loss.backward()
+    assert rel(y.detach().cpu(), g["pl/y"]) < 1e-5
+    assert abs(loss.item() - float(g["pl/loss"])) / float(g["pl/loss"]) < 1e-5
+    assert rel(xg.grad.cpu(), g["pl/grad_x"]) < 1e-5
+    assert rel(conv.weight.grad.cpu(), g["pl/grad_w"]) < 1e-5
+    assert rel(conv.bias.grad.cpu(), g["pl/grad_b"]) < 1e-5
+
+
+def test_edge_weight_forward_and_input_gradient(dev):
+    n, e, f = 500, 4000, 32
+    rng = np.random.default_rng(3)
+    src, dst = orc.powerlaw_snapshot(n, e, t=3)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    w = (rng.standard_normal((f, f)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(f).astype(np.float32)
+    ew = rng.random(e).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True)
+    y_ref = orc.graphconv_torch(src, dst, n, xt, torch.tensor(w), torch.tensor(b),
+                                edge_weight=torch.tensor(ew))
+    y_ref.sum().backward()
+    graph = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    conv = _layer(f, f, w, b, dev)
+    xg = torch.tensor(x, device=dev, requires_grad=True)
+    y = conv(graph, xg, edge_weight=torch.tensor(ew, device=dev))
+    y.sum().backward()
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xt.grad) < 1e-5
+
+
+def test_citation_graph_fixture_on_device(dev):
+    """The reference's own assertions (tests/dtdg/test_types_torch.py:45-56)."""
+    fx = np.load(os.path.join(GOLD, "types_fixture.npz"))
+    this_graph = CitationGraph(fx["edges"], fx["nodes"], fx["times"], device=dev)
+    assert len(this_graph) == len(fx["times"])
+    for i, t in enumerate(fx["expect_t"]):
+        ob, ids = this_graph.dispatcher(int(t))
+        assert ob.t == t
+        assert ob.observation.num_edges() == fx["expect_num_edges"][i]
+        assert ob.observation.num_nodes() == fx["expect_num_nodes"][i]
+        assert np.sum(ob.observation.ndata["h"].cpu().numpy()[:, -1]) == fx["expect_citation_sum"][i]
+        _, _, n, feat, _ = orc.citation_dispatch(fx["edges"], fx["nodes"], 3, int(t))
+        assert np.array_equal(ob.node_feature().cpu().numpy(), feat)
+    ob2, _ = this_graph.dispatcher(2, add_self_loop=True)
+    assert ob2.observation.num_edges() == 4 + 5
+    assert ob2.to(dev) is ob2 and ob2.to("cpu").observation.device.type == "cpu"
+
+
+def test_citation_graph_wider_features_and_cumulative_prefix(dev):
+    rng = np.random.default_rng(5)
+    n, e, steps, f = 400, 3000, 6, 5
+    node_t = np.sort(rng.integers(0, steps, n))
+    nodes = np.hstack([node_t[:, None], rng.standard_normal((n, f))])
+    a = rng.integers(0, n, e)
+    b = rng.integers(0, n, e)
+    s, d = np.maximum(a, b), np.minimum(a, b)
+    et = node_t[s]
+    order = np.argsort(et, kind="stable")
+    edges = np.stack([et, s, d], 1)[order].astype(np.float64)
+    cg = CitationGraph(edges, nodes, np.arange(steps), device=dev)
+    for t in range(steps):
+        snap, ids = cg.dispatcher(t)
+        src, dst, nn, feat, _ = orc.citation_dispatch(edges, nodes, steps, t)
+        assert snap.num_nodes() == nn and snap.observation.num_edges() == len(src)
+        assert np.array_equal(snap.node_feature().cpu().numpy(), feat)
+        assert snap.num_node_features() == f  # f-1 stored features kept + citation
+        assert np.array_equal(snap.observation.in_degrees().cpu().numpy(), orc.degree(dst, nn))
