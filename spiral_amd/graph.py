@@ -28,6 +28,16 @@ HEAVY_CHUNK = 256   # nonzeros per chunk (one workgroup, four waves of 64)
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
 
+# Optional launch timing of the aggregation (bench.py): when a list is installed, every
+# call of `aggregate` appends (start_event, end_event, nnz, n_rows, F) recorded on the
+# stream the kernels are launched on.
+_launch_log: Optional[list] = None
+
+
+def set_launch_log(log: Optional[list]) -> None:
+    global _launch_log
+    _launch_log = log
+
 
 def _i64(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.int64 else t.to(torch.int64)
@@ -146,12 +156,18 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
         raise nv.SpmiError("bad `out` tensor")
     with torch.cuda.device(x.device):
         partial = csr.partial_ws(feat)
+        if _launch_log is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         nv.check(nv.lib().spmi_gcn_spmm(
             nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.n_cols, csr.nnz,
             nv.ptr(x), x.stride(0), feat, nv.ptr(src_scale), nv.ptr(edge_w), nv.ptr(dst_scale),
             nv.ptr(bias), _ACT_CODES[act], float(slope), nv.ptr(out), out.stride(0),
             nv.ptr(csr.heavy_rows), nv.ptr(csr.heavy_chunk_ptr), csr.n_heavy, csr.n_chunks,
             csr.heavy_thresh, csr.chunk, nv.ptr(partial), nv.stream()), "spmi_gcn_spmm")
+        if _launch_log is not None:
+            ev1.record()
+            _launch_log.append((ev0, ev1, csr.nnz, csr.n_rows, feat))
     return out
 
 

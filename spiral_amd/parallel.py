@@ -1,0 +1,226 @@
+"""One snapshot across the GPUs of a node: destination-row blocks, one process per GPU.
+
+The reference has no distributed code; this is the part of the path that shards.  Rank q
+owns a contiguous block of destination nodes (cut at equal numbers of nonzeros, because
+degrees are power-law), the rows of X, of the node memory and of the output for those
+nodes, and the CSR rows of that block.  Per GCN layer there is exactly one exchange:
+
+  forward   all-gather of the source feature rows over RCCL/xGMI, then the local fused
+            aggregation over this rank's rows (indices address the gathered matrix);
+  backward  the local transposed aggregation produces a partial gradient for every
+            source row; reduce-scatter sums the partials and hands each rank its rows.
+
+Weight and bias gradients are summed with one all-reduce after the backward
+(`allreduce_gradients`).  The recurrent update and the MLP are row-local: no exchange.
+
+Blocks are padded to the largest block so that one `all_gather_into_tensor` /
+`reduce_scatter_tensor` moves everything; source ids are remapped once per snapshot to
+rows of the padded gathered matrix, so no compaction pass runs after the collective.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import graph as G
+from . import ops
+
+# Kernel entry points used below.  They are the libspmi-backed functions; the CPU tests of
+# the exchange logic (gloo, no GPU) substitute checker implementations here.
+kernels = SimpleNamespace(build_csr=G.build_csr, aggregate=G.aggregate, degree=G.degree,
+                          act_bias_bwd=ops._act_bias_bwd)
+
+
+def edge_balanced_bounds(in_degree: torch.Tensor, world: int) -> List[int]:
+    """Row cuts [b_0=0, ..., b_world=N] such that every block holds about E/world nonzeros."""
+    n = in_degree.numel()
+    if world == 1 or n == 0:
+        return [0] + [n] * world
+    csum = torch.cumsum(in_degree.to(torch.int64), 0)
+    total = int(csum[-1])
+    targets = torch.arange(1, world, dtype=torch.int64, device=csum.device) * total // world
+    cuts = (torch.searchsorted(csum, targets, right=False) + 1).clamp_(max=n).tolist()
+    bounds = [0] + cuts + [n]
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+@dataclass
+class RowPartition:
+    """Block bounds shared by all ranks plus this rank's position."""
+
+    n: int
+    bounds: List[int]
+    rank: int
+    world: int
+
+    @property
+    def max_block(self) -> int:
+        return max(self.bounds[q + 1] - self.bounds[q] for q in range(self.world))
+
+    @property
+    def n_gather(self) -> int:
+        return self.world * self.max_block
+
+    def block(self, q: Optional[int] = None):
+        q = self.rank if q is None else q
+        return self.bounds[q], self.bounds[q + 1]
+
+    def padded_rows(self, ids: torch.Tensor) -> torch.Tensor:
+        """Global node id -> row of the padded gathered matrix [world * max_block, F]."""
+        b = torch.tensor(self.bounds, dtype=torch.int64, device=ids.device)
+        q = torch.bucketize(ids, b[1:-1], right=True)
+        return q * self.max_block + ids - b[q]
+
+
+def _gather_rows(x_local: torch.Tensor, part: RowPartition, group) -> torch.Tensor:
+    f = x_local.shape[1]
+    send = x_local
+    if x_local.shape[0] != part.max_block or not x_local.is_contiguous():
+        send = x_local.new_zeros(part.max_block, f)
+        send[: x_local.shape[0]] = x_local
+    out = x_local.new_empty(part.n_gather, f)
+    dist.all_gather_into_tensor(out, send, group=group)
+    return out
+
+
+def _scatter_sum_rows(g_full: torch.Tensor, part: RowPartition, group) -> torch.Tensor:
+    out = g_full.new_empty(part.max_block, g_full.shape[1])
+    dist.reduce_scatter_tensor(out, g_full.contiguous(), group=group)
+    lo, hi = part.block()
+    return out[: hi - lo]
+
+
+class ShardedSnapshot:
+    """This rank's destination block of one snapshot."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, part: RowPartition, group=None):
+        """src/dst: the edges whose destination lies in this rank's block (global ids)."""
+        self.part, self.group = part, group
+        lo, hi = part.block()
+        self.n_local = hi - lo
+        self.src_rows = part.padded_rows(src.to(torch.int64))
+        self.dst_rows = dst.to(torch.int64) - lo
+        self._csr = self._csr_t = None
+        self._norms = {}
+
+    @classmethod
+    def from_global(cls, src, dst, part: RowPartition, group=None) -> "ShardedSnapshot":
+        """Keep the edges of a full edge list that end in this rank's block."""
+        lo, hi = part.block()
+        keep = (dst >= lo) & (dst < hi)
+        return cls(src[keep], dst[keep], part, group)
+
+    def csr(self):
+        if self._csr is None:
+            self._csr = kernels.build_csr(self.dst_rows, self.src_rows, self.n_local,
+                                          self.part.n_gather)
+        return self._csr
+
+    def csr_t(self):
+        if self._csr_t is None:
+            self._csr_t = kernels.build_csr(self.src_rows, self.dst_rows, self.part.n_gather,
+                                            self.n_local)
+        return self._csr_t
+
+    def norm(self, side: str, mode: int) -> torch.Tensor:
+        """'in': this block's destination normaliser (local rows are complete).
+        'out': source normaliser for every row of the gathered matrix; out-degrees are
+        partial per rank and summed with one all-reduce."""
+        key = (side, mode)
+        if key not in self._norms:
+            if side == "in":
+                deg = self.csr().degrees()
+            else:
+                deg = kernels.degree(self.src_rows, self.part.n_gather)
+                if self.part.world > 1:
+                    dist.all_reduce(deg, group=self.group)
+            d = deg.to(torch.float32).clamp_(min=1)
+            self._norms[key] = d.sqrt_().reciprocal_() if mode == 0 else d.reciprocal_()
+        return self._norms[key]
+
+
+class _ShardedAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, bias, shard: ShardedSnapshot, src_scale, dst_scale, act, slope):
+        xg = _gather_rows(x_local.detach(), shard.part, shard.group)
+        y = kernels.aggregate(shard.csr(), xg, src_scale, None, dst_scale,
+                              None if bias is None else bias.detach(), act, slope)
+        ctx.shard, ctx.src_scale, ctx.dst_scale = shard, src_scale, dst_scale
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        ctx.save_for_backward(y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        (y,) = ctx.saved_tensors
+        shard = ctx.shard
+        need_b = ctx.needs_input_grad[1] and ctx.has_bias
+        g_p, g_b = g_y, None
+        if y is not None or need_b:
+            g_p, g_b = kernels.act_bias_bwd(g_y, y if y is not None else g_y, ctx.act, ctx.slope,
+                                            need_b)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_full = kernels.aggregate(shard.csr_t(), g_p.contiguous(), ctx.dst_scale, None,
+                                       ctx.src_scale, None, None)
+            g_x = _scatter_sum_rows(g_full, shard.part, shard.group)
+        return g_x, g_b, None, None, None, None, None
+
+
+def sharded_aggregate(shard: ShardedSnapshot, x_local: torch.Tensor, src_scale=None,
+                      dst_scale=None, bias=None, act=None, slope: float = 0.01) -> torch.Tensor:
+    """Y_local = act(dst_scale * A_local (src_scale * allgather(X_local)) + bias)."""
+    return _ShardedAggregate.apply(x_local, bias, shard, src_scale, dst_scale, act, slope)
+
+
+def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) -> torch.Tensor:
+    """A spiral_amd GraphConv layer applied to this rank's rows of a sharded snapshot:
+    same parameters and order of operations as GraphConv.forward, with the all-gather in
+    front of the aggregation (after X W when in_feats > out_feats, so the smaller matrix
+    travels)."""
+    from .nn.graphconv import _classify_activation
+    import torch.nn.functional as F
+
+    norm = conv._norm
+    mode = 0 if norm == "both" else 1
+    src_scale = shard.norm("out", mode) if norm in ("left", "both") else None
+    dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
+    code, slope, unfused = _classify_activation(conv._activation)
+    weight = conv.weight
+    if conv._in_feats > conv._out_feats:
+        if weight is not None:
+            feat_local = feat_local @ weight
+        rst = sharded_aggregate(shard, feat_local, src_scale, dst_scale, conv.bias, code, slope)
+    else:
+        rst = sharded_aggregate(shard, feat_local, src_scale, dst_scale)
+        if weight is not None:
+            rst = torch.addmm(conv.bias, rst, weight) if conv.bias is not None else rst @ weight
+        elif conv.bias is not None:
+            rst = rst + conv.bias
+        if code == "relu":
+            rst = F.relu(rst)
+        elif code == "leaky_relu":
+            rst = F.leaky_relu(rst, slope)
+    if unfused is not None:
+        rst = unfused(rst)
+    return rst
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None) -> None:
+    """Sum parameter gradients over ranks in one flat all-reduce (they are a few KB-MB).
+    Every rank computed the loss over its own rows, so the sum is the full gradient."""
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off: off + g.numel()].view_as(g))
+        off += g.numel()
