@@ -70,14 +70,15 @@ int spmi_degree(const int64_t* ids /*device [E]*/, int64_t E, int64_t N,
  * `key` (pass dst for the by-destination CSR used by the forward, src for
  * the by-source CSR used by the backward); inside a row the entries keep the
  * original edge order (stable), `indices[j]` is the other endpoint and
- * `eid[j]` the original edge position.  indptr has N+1 entries.
+ * `eid[j]` the original edge position (eid may be NULL when edge ids are not
+ * needed: one payload less travels through the sort).  indptr has N+1 entries.
  * Implemented as a stable LSB radix sort (<= 8-bit digits) + run boundaries.
  * ---------------------------------------------------------------------- */
 size_t spmi_coo_to_csr_workspace_bytes(int64_t E, int64_t N);
 int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*device [E]*/,
                     int64_t E, int64_t N /*key range*/, int64_t N_other /*other range*/,
                     int32_t* indptr /*device [N+1]*/, int32_t* indices /*device [E]*/,
-                    int32_t* eid /*device [E]*/, void* ws, size_t ws_bytes,
+                    int32_t* eid /*nullable, device [E]*/, void* ws, size_t ws_bytes,
                     int32_t* status /*device [1]*/, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -55,11 +55,15 @@ def main():
     x = torch.randn(a.n, a.f, device=dev)
     ss, ds = csr_t.norm(0), csr.norm(0)
     bias = torch.zeros(a.f, device=dev)
+    ew = ss.index_select(0, csr.indices)
+    med, best = timed(lambda: ss.index_select(0, csr.indices), 5)
+    print(f'edge weight gather: {med:.3f} ms')
     out = torch.empty(a.n, a.f, device=dev)
     bytes_alg = a.e * (a.f * 4 + 4) + (a.n + 1) * 4 + 2 * a.n * 4 + a.n * a.f * 4 + a.f * 4
     for name, fn in (
         ("spmm plain", lambda: G.aggregate(csr, x, out=out)),
         ("spmm fused norm+bias+act", lambda: G.aggregate(csr, x, ss, None, ds, bias, "leaky_relu", 0.01, out=out)),
+        ("spmm fused, per-edge weight stream", lambda: G.aggregate(csr, x, None, ew, ds, bias, "leaky_relu", 0.01, out=out)),
     ):
         med, best = timed(fn, a.iters)
         print(f"{name}: median {med:.3f} ms best {best:.3f} ms  {a.e/med/1e6:.2f} Gedges/s  "

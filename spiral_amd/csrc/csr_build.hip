@@ -6,8 +6,8 @@
 // (types.py:241) and the degree/norm lines of dgl GraphConv.forward (call sites
 // spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:113,116).
 //
-// Design: one stable LSB radix sort of (key = row id, value = edge position)
-// with digits of at most 8 bits.  Per pass: a per-tile digit histogram, a
+// Design: one stable LSB radix sort of (key = row id; values = other endpoint and,
+// when wanted, edge position) with digits of at most 8 bits.  Per pass: a per-tile digit histogram, a
 // per-digit scan over tiles, and a scatter that ranks keys inside the tile with
 // wave ballots (stable, no atomics on the data path), stages the tile in LDS in
 // digit order and writes each digit run coalesced.  Row pointers then fall out
@@ -119,20 +119,24 @@ __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restri
 }
 
 // ---- pass kernel 3: stable scatter ------------------------------------------------
-// FIRST: keys come from the caller (range-checked) and the value is the key's
-// position.  HAS_VAL: carry a 32-bit value with each key.
-template <typename KeyT, bool FIRST, bool HAS_VAL>
+// NVAL 32-bit values travel with each key: value 0 is the other endpoint of the edge,
+// value 1 the original edge position.  FIRST: keys and value 0 come from the caller's
+// int64 arrays (range-checked) and value 1 is the position itself.
+template <typename KeyT, bool FIRST, int NVAL>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
-    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t E, uint32_t N,
-    int shift, int bits, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-    int n_tiles, int32_t* status) {
+    const KeyT* __restrict__ keys_in, const KeyT* __restrict__ other_in,
+    const uint32_t* __restrict__ v0_in, const uint32_t* __restrict__ v1_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ v0_out, uint32_t* __restrict__ v1_out,
+    int64_t E, uint32_t N, uint32_t n_other, int shift, int bits,
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, int n_tiles,
+    int32_t* status) {
   __shared__ uint32_t s_cnt[kWaves][kMaxDigits];
   __shared__ uint32_t s_dstart[kMaxDigits];
   __shared__ uint32_t s_goff[kMaxDigits];
   __shared__ uint32_t s_wave[kWaves];
   __shared__ uint32_t s_keys[kTile];
-  __shared__ uint32_t s_vals[HAS_VAL ? kTile : 1];
+  __shared__ uint32_t s_v0[NVAL >= 1 ? kTile : 1];
+  __shared__ uint32_t s_v1[NVAL >= 2 ? kTile : 1];
 
   const int ndig = 1 << bits;
   const uint32_t mask = ndig - 1;
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
   const int tile_count = tile_left < kTile ? static_cast<int>(tile_left) : kTile;
 
   uint32_t key[kKeysPerThread];
-  uint32_t val[kKeysPerThread];
+  uint32_t val0[kKeysPerThread];
+  uint32_t val1[kKeysPerThread];
   uint32_t rank[kKeysPerThread];
   const uint64_t lanes_below = (1ull << lane) - 1ull;
 
@@ -157,18 +162,20 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
   for (int j = 0; j < kKeysPerThread; ++j) {
     const int64_t i = wave_base + j * 64 + lane;
     const bool valid = i < E;
-    uint32_t k = 0, v = 0;
+    uint32_t k = 0, a = 0, b = 0;
     if (valid) {
       k = checked_key(keys_in[i], N, status);
-      if constexpr (HAS_VAL) v = FIRST ? static_cast<uint32_t>(i) : vals_in[i];
+      if constexpr (NVAL >= 1) a = FIRST ? checked_key(other_in[i], n_other, status) : v0_in[i];
+      if constexpr (NVAL >= 2) b = FIRST ? static_cast<uint32_t>(i) : v1_in[i];
     }
     key[j] = k;
-    val[j] = v;
+    val0[j] = a;
+    val1[j] = b;
     const uint32_t d = (k >> shift) & mask;
     // lanes of this wave row that hold the same digit
     uint64_t same = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-      const bool bit = (d >> b) & 1u;
+    for (int bb = 0; bb < bits; ++bb) {
+      const bool bit = (d >> bb) & 1u;
       const uint64_t bal = __ballot(valid && bit);
       same &= bit ? bal : ~bal;
     }
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
       const uint32_t d = (key[j] >> shift) & mask;
       const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[j];
       s_keys[pos] = key[j];
-      if constexpr (HAS_VAL) s_vals[pos] = val[j];
+      if constexpr (NVAL >= 1) s_v0[pos] = val0[j];
+      if constexpr (NVAL >= 2) s_v1[pos] = val1[j];
     }
   }
   __syncthreads();
@@ -222,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
       const uint32_t d = (k >> shift) & mask;
       const uint32_t g = s_goff[d] + (static_cast<uint32_t>(i) - s_dstart[d]);
       keys_out[g] = k;
-      if constexpr (HAS_VAL) vals_out[g] = s_vals[i];
+      if constexpr (NVAL >= 1) v0_out[g] = s_v0[i];
+      if constexpr (NVAL >= 2) v1_out[g] = s_v1[i];
     }
   }
 }
@@ -245,11 +254,9 @@ __device__ __forceinline__ void wave_fill_gaps(int32_t* indptr, int64_t start, i
   }
 }
 
-template <typename OtherT, bool HAS_OTHER>
-__global__ __launch_bounds__(kThreads) void csr_finalize_kernel(
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ eid,
-    const OtherT* __restrict__ other, int64_t E, int64_t N, uint32_t n_other,
-    int32_t* __restrict__ indptr, int32_t* __restrict__ indices, int32_t* status) {
+__global__ __launch_bounds__(kThreads) void csr_finalize_kernel(const uint32_t* __restrict__ keys,
+                                                                int64_t E, int64_t N,
+                                                                int32_t* __restrict__ indptr) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   const bool valid = i < E;
   int64_t k = 0, prev = -1;
@@ -267,9 +274,6 @@ __global__ __launch_bounds__(kThreads) void csr_finalize_kernel(
   // rows after the last key (and indptr[N]) point at E
   const bool last = valid && (i == E - 1);
   wave_fill_gaps(indptr, k + 1, last ? (N - k) : 0, static_cast<int32_t>(E));
-  if constexpr (HAS_OTHER) {
-    if (valid) indices[i] = static_cast<int32_t>(checked_key(other[eid[i]], n_other, status));
-  }
 }
 
 __global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
@@ -362,15 +366,16 @@ SortShape sort_shape(int64_t E, int64_t N) {
 
 struct SortBuffers {
   uint32_t* keys[2];
-  uint32_t* vals[2];  // vals[0] is the caller's eid output
+  uint32_t* v0[2];  // v0[0] is the caller's indices output
+  uint32_t* v1[2];  // v1[0] is the caller's eid output
   uint32_t* hist;
   uint32_t* totals;
 };
 
-// Sorts E keys; the result lands in keys[0] / vals[0].
-template <bool HAS_VAL>
-int run_sort(const int64_t* keys_in, int64_t E, int64_t N, const SortShape& sh,
-             const SortBuffers& b, int32_t* status, hipStream_t stream) {
+// Sorts E keys (with NVAL values each); the result lands in keys[0] / v0[0] / v1[0].
+template <int NVAL>
+int run_sort(const int64_t* keys_in, const int64_t* other_in, int64_t E, int64_t N, int64_t N_other,
+             const SortShape& sh, const SortBuffers& b, int32_t* status, hipStream_t stream) {
   int shift = 0;
   for (int p = 0; p < sh.passes; ++p) {
     const int bits = sh.pass_bits[p];
@@ -388,13 +393,13 @@ int run_sort(const int64_t* keys_in, int64_t E, int64_t N, const SortShape& sh,
     radix_scan_kernel<<<dim3(1 << bits), block, 0, stream>>>(b.hist, sh.n_tiles, b.totals);
     SPMI_CHECK_LAUNCH("radix_scan");
     if (p == 0) {
-      radix_scatter_kernel<int64_t, true, HAS_VAL><<<grid, block, 0, stream>>>(
-          keys_in, nullptr, b.keys[out], b.vals[out], E, (uint32_t)N, shift, bits, b.hist,
-          b.totals, sh.n_tiles, status);
+      radix_scatter_kernel<int64_t, true, NVAL><<<grid, block, 0, stream>>>(
+          keys_in, other_in, nullptr, nullptr, b.keys[out], b.v0[out], b.v1[out], E, (uint32_t)N,
+          (uint32_t)N_other, shift, bits, b.hist, b.totals, sh.n_tiles, status);
     } else {
-      radix_scatter_kernel<uint32_t, false, HAS_VAL><<<grid, block, 0, stream>>>(
-          b.keys[in], b.vals[in], b.keys[out], b.vals[out], E, (uint32_t)N, shift, bits, b.hist,
-          b.totals, sh.n_tiles, status);
+      radix_scatter_kernel<uint32_t, false, NVAL><<<grid, block, 0, stream>>>(
+          b.keys[in], nullptr, b.v0[in], b.v1[in], b.keys[out], b.v0[out], b.v1[out], E,
+          (uint32_t)N, (uint32_t)N_other, shift, bits, b.hist, b.totals, sh.n_tiles, status);
     }
     SPMI_CHECK_LAUNCH("radix_scatter");
     shift += bits;
@@ -424,7 +429,7 @@ extern "C" {
 size_t spmi_coo_to_csr_workspace_bytes(int64_t E, int64_t N) {
   if (E < 0 || N < 1) return 0;
   const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
-  return 3 * e4 + sort_scratch_bytes(E, N);
+  return 4 * e4 + sort_scratch_bytes(E, N);
 }
 
 int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N,
@@ -439,7 +444,7 @@ int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t
     SPMI_CHECK_HIP(hipMemsetAsync(indptr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
     return SPMI_OK;
   }
-  SPMI_REQUIRE(key && other && indices && eid && ws, SPMI_ERR_INVALID_ARG,
+  SPMI_REQUIRE(key && other && indices && ws, SPMI_ERR_INVALID_ARG,
                "spmi_coo_to_csr: null pointer argument");
   SPMI_REQUIRE(ws_bytes >= spmi_coo_to_csr_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
                "spmi_coo_to_csr: workspace %zu < required %zu", ws_bytes,
@@ -450,15 +455,18 @@ int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t
   SortBuffers b{};
   b.keys[0] = reinterpret_cast<uint32_t*>(p);
   b.keys[1] = reinterpret_cast<uint32_t*>(p + e4);
-  b.vals[0] = reinterpret_cast<uint32_t*>(eid);
-  b.vals[1] = reinterpret_cast<uint32_t*>(p + 2 * e4);
-  b.hist = reinterpret_cast<uint32_t*>(p + 3 * e4);
+  b.v0[0] = reinterpret_cast<uint32_t*>(indices);
+  b.v0[1] = reinterpret_cast<uint32_t*>(p + 2 * e4);
+  b.v1[0] = reinterpret_cast<uint32_t*>(eid);
+  b.v1[1] = reinterpret_cast<uint32_t*>(p + 3 * e4);
+  b.hist = reinterpret_cast<uint32_t*>(p + 4 * e4);
   b.totals = reinterpret_cast<uint32_t*>(
-      p + 3 * e4 + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
-  if (int rc = run_sort<true>(key, E, N, sh, b, status, st)) return rc;
+      p + 4 * e4 + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
+  const int rc = eid ? run_sort<2>(key, other, E, N, N_other, sh, b, status, st)
+                     : run_sort<1>(key, other, E, N, N_other, sh, b, status, st);
+  if (rc) return rc;
   const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
-  csr_finalize_kernel<int64_t, true><<<grid, kThreads, 0, st>>>(
-      b.keys[0], b.vals[0], other, E, N, (uint32_t)N_other, indptr, indices, status);
+  csr_finalize_kernel<<<grid, kThreads, 0, st>>>(b.keys[0], E, N, indptr);
   SPMI_CHECK_LAUNCH("csr_finalize");
   return SPMI_OK;
 }
@@ -489,15 +497,14 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
   SortBuffers b{};
   b.keys[0] = reinterpret_cast<uint32_t*>(p);
   b.keys[1] = reinterpret_cast<uint32_t*>(p + e4);
-  b.vals[0] = b.vals[1] = nullptr;
+  b.v0[0] = b.v0[1] = b.v1[0] = b.v1[1] = nullptr;
   int32_t* indptr = reinterpret_cast<int32_t*>(p + 2 * e4);
   b.hist = reinterpret_cast<uint32_t*>(p + 2 * e4 + np);
   b.totals = reinterpret_cast<uint32_t*>(
       p + 2 * e4 + np + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
-  if (int rc = run_sort<false>(ids, E, N, sh, b, status, st)) return rc;
+  if (int rc = run_sort<0>(ids, nullptr, E, N, 1, sh, b, status, st)) return rc;
   const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
-  csr_finalize_kernel<int64_t, false><<<grid, kThreads, 0, st>>>(
-      b.keys[0], nullptr, nullptr, E, N, 0u, indptr, nullptr, status);
+  csr_finalize_kernel<<<grid, kThreads, 0, st>>>(b.keys[0], E, N, indptr);
   SPMI_CHECK_LAUNCH("csr_finalize(degree)");
   indptr_to_degree_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, deg);
   SPMI_CHECK_LAUNCH("indptr_to_degree");

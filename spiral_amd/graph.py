@@ -49,7 +49,7 @@ class CSR:
 
     indptr: torch.Tensor
     indices: torch.Tensor
-    eid: torch.Tensor
+    eid: Optional[torch.Tensor]  # original edge positions; None unless asked for
     n_rows: int
     n_cols: int
     nnz: int
@@ -82,9 +82,11 @@ class CSR:
 
 
 def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
-              heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK) -> CSR:
+              heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
+              want_eid: bool = False) -> CSR:
     """COO -> CSR grouped by `key` plus the aggregation plan (one host sync to read the
-    status word and the plan sizes)."""
+    status word and the plan sizes).  Edge ids travel through the sort only when
+    `want_eid` (edge weights / edge features need them; plain GCN does not)."""
     nv.require_cuda(key, other)
     key, other = _i64(key).contiguous(), _i64(other).contiguous()
     dev = key.device
@@ -93,7 +95,7 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
     with torch.cuda.device(dev):
         indptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
         indices = torch.empty(e, dtype=torch.int32, device=dev)
-        eid = torch.empty(e, dtype=torch.int32, device=dev)
+        eid = torch.empty(e, dtype=torch.int32, device=dev) if want_eid else None
         meta = torch.zeros(3, dtype=torch.int32, device=dev)  # status, n_heavy, n_chunks
         ws_bytes = lib.spmi_coo_to_csr_workspace_bytes(e, n_key)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -171,6 +173,41 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
     return out
 
 
+class NormalisedAdjacency:
+    """What the aggregation needs from a graph object: csr() / csr_t() / norm(side, mode).
+    On top of those this mixin caches the per-nonzero weights the fused kernel streams
+    in CSR order, so that the source-side normaliser is a coalesced 4-byte stream per
+    edge instead of a dependent random gather inside the kernel."""
+
+    def _edge_scale_cache(self) -> dict:
+        cache = getattr(self, "_edge_scales", None)
+        if cache is None:
+            cache = self._edge_scales = {}
+        return cache
+
+    def edge_scale(self, direction: str, norm: str, edge_weight: Optional[torch.Tensor] = None
+                   ) -> Optional[torch.Tensor]:
+        """Weights w_j in CSR order.  'fwd': by-destination CSR, w_j = norm_out[src_j] for
+        norm in ('left','both'); 'bwd': by-source CSR, w_j = norm_in[dst_j] for norm in
+        ('right','both').  A user edge weight (edge-id order) is permuted and multiplied in."""
+        mode = 0 if norm == "both" else 1
+        if direction == "fwd":
+            scaled, side = norm in ("left", "both"), "out"
+        else:
+            scaled, side = norm in ("right", "both"), "in"
+        key = (direction, norm)
+        cache = self._edge_scale_cache()
+        w = cache.get(key)
+        if w is None and scaled:
+            csr = self.csr() if direction == "fwd" else self.csr_t()
+            w = cache[key] = self.norm(side, mode).index_select(0, csr.indices)
+        if edge_weight is not None:
+            csr = self.csr(want_eid=True) if direction == "fwd" else self.csr_t(want_eid=True)
+            p = edge_weight.detach().to(torch.float32).reshape(-1).index_select(0, csr.eid)
+            w = p if w is None else w * p
+        return w
+
+
 class _FrameDict(dict):
     """ndata / edata: feature name -> tensor, checked against the number of rows."""
 
@@ -185,7 +222,7 @@ class _FrameDict(dict):
         super().__setitem__(key, value)
 
 
-class SnapshotGraph:
+class SnapshotGraph(NormalisedAdjacency):
     """Stand-in for the `dgl.DGLGraph` of one snapshot (homogeneous, directed, multi-edges
     and self-loops kept, edge ids = positions in the COO list)."""
 
@@ -260,14 +297,14 @@ class SnapshotGraph:
         return g
 
     # ---- device structures ------------------------------------------------------------
-    def csr(self) -> CSR:
-        if self._csr is None:
-            self._csr = build_csr(self._dst, self._src, self._n, self._n)
+    def csr(self, want_eid: bool = False) -> CSR:
+        if self._csr is None or (want_eid and self._csr.eid is None):
+            self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid)
         return self._csr
 
-    def csr_t(self) -> CSR:
-        if self._csr_t is None:
-            self._csr_t = build_csr(self._src, self._dst, self._n, self._n)
+    def csr_t(self, want_eid: bool = False) -> CSR:
+        if self._csr_t is None or (want_eid and self._csr_t.eid is None):
+            self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid)
         return self._csr_t
 
     def norm(self, side: str, mode: int) -> torch.Tensor:

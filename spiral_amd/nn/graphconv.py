@@ -82,17 +82,14 @@ class GraphConv(nn.Module):
         else:
             weight = self.weight
 
-        mode = 0 if self._norm == "both" else 1
-        src_scale = graph.norm("out", mode) if self._norm in ("left", "both") else None
-        dst_scale = graph.norm("in", mode) if self._norm in ("right", "both") else None
         code, slope, unfused = _classify_activation(self._activation)
 
         if self._in_feats > self._out_feats:
             if weight is not None:
                 feat = feat @ weight
-            rst = gcn_aggregate(graph, feat, src_scale, dst_scale, self.bias, edge_weight, code, slope)
+            rst = gcn_aggregate(graph, feat, self._norm, self.bias, edge_weight, code, slope)
         else:
-            rst = gcn_aggregate(graph, feat, src_scale, dst_scale, None, edge_weight, None)
+            rst = gcn_aggregate(graph, feat, self._norm, None, edge_weight, None)
             if weight is not None:
                 rst = torch.addmm(self.bias, rst, weight) if self.bias is not None else rst @ weight
             elif self.bias is not None:

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _native as nv
-from .graph import SnapshotGraph, aggregate
+from .graph import aggregate
 
 
 def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope: float,
@@ -35,16 +35,16 @@ def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope:
 class GcnAggregate(torch.autograd.Function):
     """Y = act(norm_dst * A (norm_src * X) + bias) with A the snapshot's adjacency
     (rows = destinations).  Backward runs the same kernel on the by-source CSR with the
-    two normalisers exchanged: dX = norm_src * A^T (norm_dst * dP)."""
+    two normalisers exchanged: dX = norm_src * A^T (norm_dst * dP).  `g` is any
+    NormalisedAdjacency (a SnapshotGraph, or one rank's shard of it)."""
 
     @staticmethod
-    def forward(ctx, x, bias, g: SnapshotGraph, src_scale, dst_scale, edge_weight, act, slope):
-        csr = g.csr()
-        ew = None if edge_weight is None else edge_weight.detach()[csr.eid.long()].contiguous()
-        y = aggregate(csr, x.detach(), src_scale, ew, dst_scale,
+    def forward(ctx, x, bias, g, norm, edge_weight, act, slope):
+        mode = 0 if norm == "both" else 1
+        dst_scale = g.norm("in", mode) if norm in ("right", "both") else None
+        y = aggregate(g.csr(), x.detach(), None, g.edge_scale("fwd", norm, edge_weight), dst_scale,
                       None if bias is None else bias.detach(), act, slope)
-        ctx.g, ctx.src_scale, ctx.dst_scale = g, src_scale, dst_scale
-        ctx.edge_weight, ctx.act, ctx.slope = edge_weight, act, slope
+        ctx.g, ctx.norm, ctx.edge_weight, ctx.act, ctx.slope = g, norm, edge_weight, act, slope
         ctx.has_bias = bias is not None
         ctx.save_for_backward(y if act not in (None, "none") else None)
         return y
@@ -58,21 +58,21 @@ class GcnAggregate(torch.autograd.Function):
             g_p, g_b = _act_bias_bwd(g_y, y if y is not None else g_y, ctx.act, ctx.slope, need_b)
         g_x = None
         if need_x:
-            csr_t = ctx.g.csr_t()
-            ew = None
-            if ctx.edge_weight is not None:
-                ew = ctx.edge_weight.detach()[csr_t.eid.long()].contiguous()
-            g_x = aggregate(csr_t, g_p, ctx.dst_scale, ew, ctx.src_scale, None, None)
-        return g_x, g_b, None, None, None, None, None, None
+            g, norm = ctx.g, ctx.norm
+            mode = 0 if norm == "both" else 1
+            out_scale = g.norm("out", mode) if norm in ("left", "both") else None
+            g_x = aggregate(g.csr_t(), g_p.contiguous(), None,
+                            g.edge_scale("bwd", norm, ctx.edge_weight), out_scale, None, None)
+        return g_x, g_b, None, None, None, None, None
 
 
-def gcn_aggregate(g: SnapshotGraph, x: torch.Tensor, src_scale: Optional[torch.Tensor] = None,
-                  dst_scale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+def gcn_aggregate(g, x: torch.Tensor, norm: str = "both", bias: Optional[torch.Tensor] = None,
                   edge_weight: Optional[torch.Tensor] = None, act: Optional[str] = None,
                   slope: float = 0.01) -> torch.Tensor:
+    """Differentiable fused aggregation over graph `g` with DGL GraphConv's `norm` modes."""
     if edge_weight is not None and edge_weight.requires_grad:
         raise nv.SpmiError("gradients with respect to edge_weight are not implemented")
-    return GcnAggregate.apply(x, bias, g, src_scale, dst_scale, edge_weight, act, slope)
+    return GcnAggregate.apply(x, bias, g, norm, edge_weight, act, slope)
 
 
 # --------------------------------------------------------------------------- recurrent cells

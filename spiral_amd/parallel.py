@@ -96,7 +96,7 @@ def _scatter_sum_rows(g_full: torch.Tensor, part: RowPartition, group) -> torch.
     return out[: hi - lo]
 
 
-class ShardedSnapshot:
+class ShardedSnapshot(G.NormalisedAdjacency):
     """This rank's destination block of one snapshot."""
 
     def __init__(self, src: torch.Tensor, dst: torch.Tensor, part: RowPartition, group=None):
@@ -116,13 +116,13 @@ class ShardedSnapshot:
         keep = (dst >= lo) & (dst < hi)
         return cls(src[keep], dst[keep], part, group)
 
-    def csr(self):
+    def csr(self, want_eid: bool = False):
         if self._csr is None:
             self._csr = kernels.build_csr(self.dst_rows, self.src_rows, self.n_local,
                                           self.part.n_gather)
         return self._csr
 
-    def csr_t(self):
+    def csr_t(self, want_eid: bool = False):
         if self._csr_t is None:
             self._csr_t = kernels.build_csr(self.src_rows, self.dst_rows, self.part.n_gather,
                                             self.n_local)
@@ -147,19 +147,20 @@ class ShardedSnapshot:
 
 class _ShardedAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_local, bias, shard: ShardedSnapshot, src_scale, dst_scale, act, slope):
+    def forward(ctx, x_local, bias, shard: ShardedSnapshot, norm, act, slope):
+        mode = 0 if norm == "both" else 1
         xg = _gather_rows(x_local.detach(), shard.part, shard.group)
-        y = kernels.aggregate(shard.csr(), xg, src_scale, None, dst_scale,
+        dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
+        y = kernels.aggregate(shard.csr(), xg, None, shard.edge_scale("fwd", norm), dst_scale,
                               None if bias is None else bias.detach(), act, slope)
-        ctx.shard, ctx.src_scale, ctx.dst_scale = shard, src_scale, dst_scale
-        ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        ctx.shard, ctx.norm, ctx.act, ctx.slope, ctx.has_bias = shard, norm, act, slope, bias is not None
         ctx.save_for_backward(y if act not in (None, "none") else None)
         return y
 
     @staticmethod
     def backward(ctx, g_y):
         (y,) = ctx.saved_tensors
-        shard = ctx.shard
+        shard, norm = ctx.shard, ctx.norm
         need_b = ctx.needs_input_grad[1] and ctx.has_bias
         g_p, g_b = g_y, None
         if y is not None or need_b:
@@ -167,16 +168,18 @@ class _ShardedAggregate(torch.autograd.Function):
                                             need_b)
         g_x = None
         if ctx.needs_input_grad[0]:
-            g_full = kernels.aggregate(shard.csr_t(), g_p.contiguous(), ctx.dst_scale, None,
-                                       ctx.src_scale, None, None)
+            mode = 0 if norm == "both" else 1
+            out_scale = shard.norm("out", mode) if norm in ("left", "both") else None
+            g_full = kernels.aggregate(shard.csr_t(), g_p.contiguous(), None,
+                                       shard.edge_scale("bwd", norm), out_scale, None, None)
             g_x = _scatter_sum_rows(g_full, shard.part, shard.group)
-        return g_x, g_b, None, None, None, None, None
+        return g_x, g_b, None, None, None, None
 
 
-def sharded_aggregate(shard: ShardedSnapshot, x_local: torch.Tensor, src_scale=None,
-                      dst_scale=None, bias=None, act=None, slope: float = 0.01) -> torch.Tensor:
-    """Y_local = act(dst_scale * A_local (src_scale * allgather(X_local)) + bias)."""
-    return _ShardedAggregate.apply(x_local, bias, shard, src_scale, dst_scale, act, slope)
+def sharded_aggregate(shard: ShardedSnapshot, x_local: torch.Tensor, norm: str = "both",
+                      bias=None, act=None, slope: float = 0.01) -> torch.Tensor:
+    """Y_local = act(norm_in * A_local (norm_out * allgather(X_local)) + bias)."""
+    return _ShardedAggregate.apply(x_local, bias, shard, norm, act, slope)
 
 
 def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) -> torch.Tensor:
@@ -188,17 +191,14 @@ def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) ->
     import torch.nn.functional as F
 
     norm = conv._norm
-    mode = 0 if norm == "both" else 1
-    src_scale = shard.norm("out", mode) if norm in ("left", "both") else None
-    dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
     code, slope, unfused = _classify_activation(conv._activation)
     weight = conv.weight
     if conv._in_feats > conv._out_feats:
         if weight is not None:
             feat_local = feat_local @ weight
-        rst = sharded_aggregate(shard, feat_local, src_scale, dst_scale, conv.bias, code, slope)
+        rst = sharded_aggregate(shard, feat_local, norm, conv.bias, code, slope)
     else:
-        rst = sharded_aggregate(shard, feat_local, src_scale, dst_scale)
+        rst = sharded_aggregate(shard, feat_local, norm)
         if weight is not None:
             rst = torch.addmm(conv.bias, rst, weight) if conv.bias is not None else rst @ weight
         elif conv.bias is not None:

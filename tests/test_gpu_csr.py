@@ -12,11 +12,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_csr(src, dst, n, dev):
-    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n, want_eid=True)
     indptr, indices, eid = orc.coo_to_csr(dst, src, n)
     assert np.array_equal(csr.indptr.cpu().numpy(), indptr)
     assert np.array_equal(csr.indices.cpu().numpy(), indices)
     assert np.array_equal(csr.eid.cpu().numpy(), eid)
+    lean = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n)
+    assert lean.eid is None  # edge ids travel through the sort only on request
+    assert np.array_equal(lean.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(lean.indices.cpu().numpy(), indices)
     return csr
 
 

@@ -22,11 +22,11 @@ from spiral_amd import parallel as par
 def _cpu_kernels():
     class CpuCSR:
         def __init__(self, indptr, indices, eid, n_rows, n_cols):
-            self.indptr, self.indices, self.eid = indptr, indices, eid
+            self.indptr, self.indices, self.eid = (torch.from_numpy(a) for a in (indptr, indices, eid))
             self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, len(indices)
 
         def degrees(self):
-            return torch.from_numpy(np.diff(self.indptr).astype(np.int64))
+            return (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
 
     def build_csr(key, other, n_key, n_other, *_):
         return CpuCSR(*orc.coo_to_csr(key.numpy(), other.numpy(), n_key, n_other), n_key, n_other)
@@ -34,7 +34,7 @@ def _cpu_kernels():
     def aggregate(csr, x, src_scale=None, edge_w=None, dst_scale=None, bias=None, act=None, slope=0.01):
         n = lambda t: None if t is None else t.detach().numpy()
         assert x.shape[0] == csr.n_cols
-        return torch.from_numpy(orc.aggregate(csr.indptr, csr.indices, n(x), n(src_scale), n(edge_w),
+        return torch.from_numpy(orc.aggregate(csr.indptr.numpy(), csr.indices.numpy(), n(x), n(src_scale), n(edge_w),
                                               n(dst_scale), n(bias), act, slope))
 
     def degree(ids, n):
