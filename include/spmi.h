@@ -184,6 +184,26 @@ int spmi_rnn_gate_fwd(const float* gi /*[M,H]*/, const float* gh /*[M,H]*/, cons
 int spmi_rnn_gate_bwd(const float* gh_out /*[M,H]*/, const float* h_out /*[M,H]*/, int64_t M,
                       int64_t H, float* g_gates /*[M,H]*/, void* stream);
 
+/* ------------------------------------------------------------------------
+ * One whole recurrent layer step in one kernel: both gate GEMMs on the fp32
+ * matrix cores (exact fp32 FMA chains), gate math, node-memory read and the
+ * in-place write-back.  Same reference lines as the gate kernels above, plus
+ * the torch.nn.GRU/LSTM/RNN call itself (implicitTimeModels.py:154,225).
+ *   cell   : 0 = GRU, 1 = LSTM, 2 = RNN(tanh)
+ *   x      : [M, I] with leading dimension ldx
+ *   wt_ih  : weight_ih transposed, [I, G*H]; wt_hh: weight_hh transposed, [H, G*H]
+ *            (G = 3 / 4 / 1; torch gate order)
+ *   others : as for the gate kernels; `saved` has the same layout, so the gate
+ *            backward kernels apply unchanged.
+ * Shapes: I % 16 == 0 and H % 32 == 0 (spmi_cell_fused_supported tells);
+ * other shapes go through library GEMMs + the gate kernels.
+ * ---------------------------------------------------------------------- */
+int spmi_cell_fused_supported(int64_t I, int64_t H);
+int spmi_cell_fused_fwd(int cell, const float* x, int64_t ldx, int64_t I, const float* wt_ih,
+                        const float* wt_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

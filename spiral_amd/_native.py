@@ -43,6 +43,9 @@ _SIGNATURES = {
     "spmi_rnn_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
                                   c_vp]),
     "spmi_rnn_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "spmi_cell_fused_supported": (c_int, [c_i64, c_i64]),
+    "spmi_cell_fused_fwd": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                    c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -100,21 +100,47 @@ def _check_cell_args(x, mem, ids):
         raise nv.SpmiError("batch larger than the node memory")
 
 
+_CELL_CODE = {"gru": 0, "lstm": 1, "rnn": 2}
+USE_FUSED_CELLS = True  # one-kernel layer step when the shapes allow it (I % 16, H % 32)
+
+
+def _fused_ok(x, w_hh) -> bool:
+    return (USE_FUSED_CELLS and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(nv.lib().spmi_cell_fused_supported(x.shape[1], w_hh.shape[1])))
+
+
+def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h_out, c_out, saved):
+    """Both gate GEMMs + gates + memory write-back in one launch (csrc/cell_fused.hip)."""
+    wt_ih = w_ih.detach().t().contiguous()
+    wt_hh = w_hh.detach().t().contiguous()
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().spmi_cell_fused_fwd(
+            _CELL_CODE[kind], nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(wt_ih), nv.ptr(wt_hh),
+            nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem), nv.ptr(ids), x.shape[0],
+            w_hh.shape[1], nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
+            nv.stream()), "spmi_cell_fused_fwd")
+
+
 class GruCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        h_old = _rows(h_mem, ids, m)
-        gi = xd @ w_ih.detach().t()
-        gh = h_old @ w_hh.detach().t()
         need_grad = any(ctx.needs_input_grad[:5])
         saved = torch.empty(m, 5 * hd, dtype=torch.float32, device=x.device) if need_grad else None
         h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            nv.check(nv.lib().spmi_gru_gate_fwd(
-                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
-                hd, nv.ptr(h_out), int(mem_write), nv.ptr(saved), nv.stream()), "spmi_gru_gate_fwd")
+        if _fused_ok(xd, w_hh):
+            _fused_cell("gru", xd, w_ih, w_hh, b_ih, b_hh, h_mem, None, ids, mem_write, h_out, None,
+                        saved)
+        else:
+            h_old = _rows(h_mem, ids, m)
+            gi = xd @ w_ih.detach().t()
+            gh = h_old @ w_hh.detach().t()
+            with torch.cuda.device(x.device):
+                nv.check(nv.lib().spmi_gru_gate_fwd(
+                    nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
+                    hd, nv.ptr(h_out), int(mem_write), nv.ptr(saved), nv.stream()),
+                    "spmi_gru_gate_fwd")
         ctx.save_for_backward(xd, w_ih, w_hh, saved)
         ctx.has_bias = b_ih is not None
         return h_out
@@ -144,20 +170,25 @@ class LstmCell(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        h_old = _rows(h_mem, ids, m)
         need_grad = any(ctx.needs_input_grad[:5])
-        if need_grad and mem_write and ids is None:
+        fused = _fused_ok(xd, w_hh)
+        h_old = _rows(h_mem, ids, m) if (need_grad or not fused) else None
+        if need_grad and (mem_write or ids is not None):
             h_old = h_old.clone()  # the backward needs h_old after the memory rows are overwritten
-        gi = xd @ w_ih.detach().t()
-        gh = h_old @ w_hh.detach().t()
         saved = torch.empty(m, 6 * hd, dtype=torch.float32, device=x.device) if need_grad else None
         h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
         c_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            nv.check(nv.lib().spmi_lstm_gate_fwd(
-                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem),
-                nv.ptr(ids), m, hd, nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
-                nv.stream()), "spmi_lstm_gate_fwd")
+        if fused:
+            _fused_cell("lstm", xd, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h_out,
+                        c_out, saved)
+        else:
+            gi = xd @ w_ih.detach().t()
+            gh = h_old @ w_hh.detach().t()
+            with torch.cuda.device(x.device):
+                nv.check(nv.lib().spmi_lstm_gate_fwd(
+                    nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem),
+                    nv.ptr(ids), m, hd, nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
+                    nv.stream()), "spmi_lstm_gate_fwd")
         ctx.save_for_backward(xd, w_ih, w_hh, saved, h_old if need_grad else None)
         ctx.has_bias = b_ih is not None
         ctx.mark_non_differentiable(c_out)
@@ -185,17 +216,22 @@ class RnnCell(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        h_old = _rows(h_mem, ids, m)
         need_grad = any(ctx.needs_input_grad[:5])
-        if need_grad and mem_write and ids is None:
+        fused = _fused_ok(xd, w_hh)
+        h_old = _rows(h_mem, ids, m) if (need_grad or not fused) else None
+        if need_grad and (mem_write or ids is not None):
             h_old = h_old.clone()
-        gi = xd @ w_ih.detach().t()
-        gh = h_old @ w_hh.detach().t()
         h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            nv.check(nv.lib().spmi_rnn_gate_fwd(
-                nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
-                hd, nv.ptr(h_out), int(mem_write), nv.stream()), "spmi_rnn_gate_fwd")
+        if fused:
+            _fused_cell("rnn", xd, w_ih, w_hh, b_ih, b_hh, h_mem, None, ids, mem_write, h_out, None,
+                        None)
+        else:
+            gi = xd @ w_ih.detach().t()
+            gh = h_old @ w_hh.detach().t()
+            with torch.cuda.device(x.device):
+                nv.check(nv.lib().spmi_rnn_gate_fwd(
+                    nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(ids), m,
+                    hd, nv.ptr(h_out), int(mem_write), nv.stream()), "spmi_rnn_gate_fwd")
         ctx.save_for_backward(xd, w_ih, w_hh, h_out, h_old if need_grad else None)
         ctx.has_bias = b_ih is not None
         return h_out

@@ -73,13 +73,20 @@ def test_decoder_matches_reference_goldens(dev, kind):
     assert rel(dec.memory_h.memory.cpu(), d[f"{kind}/eval/mem_h"]) < 1e-5  # untouched in eval mode
 
 
-@pytest.mark.parametrize("hid", [10, 32, 128])
-def test_cells_against_torch_modules_with_general_ids(dev, hid):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("in_d,hid,m,identity", [(24, 10, 20, False), (24, 32, 20, False),
+                                                 (32, 32, 20, False), (48, 64, 300, False),
+                                                 (128, 128, 333, True), (64, 96, 130, False),
+                                                 (32, 256, 129, True)])
+def test_cells_against_torch_modules(dev, fused, in_d, hid, m, identity):
     """One step of each cell vs torch.nn.{GRU,LSTM,RNN} on the CPU, rows scattered in the
-    memory table, including the write-back and all gradients."""
-    torch.manual_seed(hid)
-    n_mem, m, in_d = 50, 20, 24
-    ids = torch.randperm(n_mem)[:m]
+    memory table (or the identity prefix), including the write-back and all gradients.
+    `fused` selects the one-kernel MFMA layer step where the shape allows it (in_d % 16
+    == 0 and hid % 32 == 0); otherwise library GEMMs + the gate kernel run."""
+    torch.manual_seed(hid + in_d)
+    ops.USE_FUSED_CELLS = fused
+    n_mem = m + 40
+    ids = torch.arange(m) if identity else torch.randperm(n_mem)[:m]
     for kind, mod in (("gru", torch.nn.GRU), ("lstm", torch.nn.LSTM), ("rnn", torch.nn.RNN)):
         ref = mod(in_d, hid, batch_first=True)
         x = torch.randn(m, in_d, requires_grad=True)
@@ -95,7 +102,7 @@ def test_cells_against_torch_modules_with_general_ids(dev, hid):
                   ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         xg = x.detach().clone().to(dev).requires_grad_()
         gh, gc = mem_h.to(dev).clone(), mem_c.to(dev).clone()
-        idg = ids.to(dev)
+        idg = None if identity else ids.to(dev)
         if kind == "gru":
             y = ops.gru_cell(xg, *params, gh, idg)
         elif kind == "rnn":
@@ -113,3 +120,4 @@ def test_cells_against_torch_modules_with_general_ids(dev, hid):
         assert rel(xg.grad.cpu(), x.grad) < 1e-5
         for p, n in zip(params, ("weight_ih", "weight_hh", "bias_ih", "bias_hh")):
             assert rel(p.grad.cpu(), getattr(ref, f"{n}_l0").grad) < 1e-5, (kind, n)
+    ops.USE_FUSED_CELLS = True
