@@ -195,7 +195,7 @@ int spmi_rnn_gate_bwd(const float* gh_out /*[M,H]*/, const float* h_out /*[M,H]*
  *            (G = 3 / 4 / 1; torch gate order)
  *   others : as for the gate kernels; `saved` has the same layout, so the gate
  *            backward kernels apply unchanged.
- * Shapes: I % 16 == 0 and H % 32 == 0 (spmi_cell_fused_supported tells);
+ * Shapes: I % 32 == 0 and H % 32 == 0 (spmi_cell_fused_supported tells);
  * other shapes go through library GEMMs + the gate kernels.
  * ---------------------------------------------------------------------- */
 int spmi_cell_fused_supported(int64_t I, int64_t H);

@@ -101,7 +101,7 @@ def _check_cell_args(x, mem, ids):
 
 
 _CELL_CODE = {"gru": 0, "lstm": 1, "rnn": 2}
-USE_FUSED_CELLS = True  # one-kernel layer step when the shapes allow it (I % 16, H % 32)
+USE_FUSED_CELLS = True  # one-kernel layer step when the shapes allow it (I % 32, H % 32)
 
 
 def _fused_ok(x, w_hh) -> bool:

@@ -75,7 +75,7 @@ def test_decoder_matches_reference_goldens(dev, kind):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("in_d,hid,m,identity", [(24, 10, 20, False), (24, 32, 20, False),
-                                                 (32, 32, 20, False), (48, 64, 300, False),
+                                                 (32, 32, 20, False), (64, 64, 300, False), (48, 64, 70, False),
                                                  (128, 128, 333, True), (64, 96, 130, False),
                                                  (32, 256, 129, True)])
 def test_cells_against_torch_modules(dev, fused, in_d, hid, m, identity):
