@@ -45,6 +45,18 @@ from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
+
+def measured_traffic(workload: str, world: int):
+    """HBM-side bytes per fused-aggregation launch from the committed rocprofv3 PMC run
+    (FETCH_SIZE / WRITE_SIZE in separate passes, read side calibrated on a graph of known
+    traffic: profiles/r01_spmm_traffic.json).  Counters cannot be read from inside this
+    process, so the figure is the one measured for the same workload and kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
+    if workload != "config2" or world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["traffic_bytes_per_launch"]
+
 WORKLOADS = {
     # nodes and edges PER GPU and per snapshot
     "config2": dict(n=1_000_000, e=10_000_000, f=128, hidden=128, rnn_hidden=128, snapshots=32,
@@ -274,7 +286,7 @@ def main():
             "stages": stages,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
                 "kernel": "spmm_stream_kernel<2> (+ spmm_heavy/spmm_heavy_reduce for hub rows), one fused "
                           "GraphConv aggregation launch group",
                 "avg_launch_ms": spmm_avg_ms, "launches": len(spmm_ms),
