@@ -193,7 +193,7 @@ def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) ->
     norm = conv._norm
     code, slope, unfused = _classify_activation(conv._activation)
     weight = conv.weight
-    if conv._in_feats > conv._out_feats:
+    if conv._in_feats >= conv._out_feats:
         if weight is not None:
             feat_local = feat_local @ weight
         rst = sharded_aggregate(shard, feat_local, norm, conv.bias, code, slope)
