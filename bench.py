@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--snapshots", type=int, default=0, help="distinct resident snapshots (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="train: forward + MSE loss + backward + Adam step per snapshot "
+                         "(the loop of examples/torch/citation_prediction.py:90-101)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,18 +242,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i, False)
-        launch_log = []
-        G.set_launch_log(launch_log)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i, True)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        G.set_launch_log(None)
+    train = args.mode == "train"
+    if train:
+        model.train()
+        for m in model.rnn.simple_decoder.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        label = torch.randn(n_local, device=dev)
+
+    def run(i, record):
+        if not train:
+            with torch.no_grad():
+                return step(i, record)
+        opt.zero_grad(set_to_none=True)
+        loss = F.mse_loss(step(i, record).squeeze(-1), label)
+        loss.backward()
+        if world > 1:
+            par.allreduce_gradients(model)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        run(i, False)
+    launch_log = []
+    G.set_launch_log(launch_log)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(args.warmup + i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    G.set_launch_log(None)
 
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -280,7 +303,8 @@ def main():
             "config": {"workload": w["name"] + (f", x{world} row-partitioned" if world > 1 else ""),
                        "nodes": n_total, "edges_per_snapshot": e_total, "features": f,
                        "resident_snapshots": n_snap,
-                       "step": "COO->CSR+norm, 2x GraphConv(128->128, leaky_relu), 2-layer GRU(128) + MLP, forward",
+                       "step": "COO->CSR+norm, 2x GraphConv(128->128, leaky_relu), 2-layer GRU(128) + MLP, "
+                               + ("forward + MSE + backward + Adam" if train else "forward"),
                        "parallelism": f"dst-row blocks x{world}" if world > 1 else "single GPU"},
             "aggregation_edges_per_s": mean_nnz * world / (spmm_avg_ms * 1e-3),
             "stages": stages,
