@@ -354,6 +354,50 @@ def mlp_forward(x, layers, training: bool = False, eps: float = 1e-5):
     return h
 
 
+# ----------------------------------------------------------------------------- edge task
+def process_target_ids(ids: np.ndarray):
+    """tf/sequentialDecoder/baseModel.py:32-46: rank-1 ids pass through; rank-2 (n_edges, 2)
+    pairs become (distinct nodes, pairs re-indexed into that list).  The reference keeps
+    first-occurrence order (tf.unique); the order only permutes rows that are re-indexed
+    consistently, so sorted order gives the same per-edge result."""
+    ids = np.asarray(ids)
+    if ids.ndim == 1:
+        return ids, ids
+    if ids.ndim != 2:
+        raise ValueError("ids must be of rank 1 or 2")
+    nodes, inverse = np.unique(ids.reshape(-1), return_inverse=True)
+    return nodes, inverse.reshape(-1, 2)
+
+
+def edge_head_forward(kind, embs, pairs, mem_h, params, mlp_layers, mem_c=None, sigmoid=True):
+    """Edge-task decoder forward (RnnFamily.call, tf/.../baseModel.py:154-164 + MLP.call,
+    tf/simpleDecoder.py:90-97): recurrent step on the distinct nodes of `pairs` (memory rows
+    read and written there), pair-wise concatenation, MLP (eval-mode BatchNorm), sigmoid.
+    Returns (prediction [n_edges, out], new mem_h[, new mem_c])."""
+    nodes, pid = process_target_ids(pairs)
+    x = embs[nodes]
+    if kind == "lstm":
+        out, h, c = recurrent_step(kind, x, mem_h[:, nodes], params, mem_c[:, nodes])
+        mem_c = mem_c.copy()
+        mem_c[:, nodes] = c
+    else:
+        out, h = recurrent_step(kind, x, mem_h[:, nodes], params)
+    mem_h = mem_h.copy()
+    mem_h[:, nodes] = h
+    z = out[pid.reshape(-1)].reshape(pid.shape[0], -1)
+    y = mlp_forward(z, mlp_layers, training=False)
+    if sigmoid:
+        y = _sigmoid(y)
+    return (y, mem_h, mem_c) if kind == "lstm" else (y, mem_h)
+
+
+def neg_sampling(pos_inds, n_items, n_samp, rng=np.random):
+    """spiro/core/dataio.py:29-35 (pos_inds sorted)."""
+    pos_inds = np.asarray(pos_inds)
+    raw = rng.randint(0, n_items - len(pos_inds), size=n_samp)
+    return raw + np.searchsorted(pos_inds - np.arange(len(pos_inds)), raw, side="right")
+
+
 # ----------------------------------------------------------------------------- synthetic data
 def powerlaw_snapshot(n: int, e: int, t: int = 0, k_dst: float = 3.0, k_src: float = 1.5,
                       perm: Optional[np.ndarray] = None):

@@ -1,0 +1,71 @@
+"""Edge-task (link prediction) preparation; API of spiro/automl/tf/prepare_dataset.py:37-94,
+which the reference only ships for its TensorFlow backend.  The sampling itself is
+host-side numpy with the same draws (np.random) as the reference; successor lists come
+from one copy of the snapshot's by-source CSR instead of a graph query per node."""
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from spiral_amd.core.dataio import neg_sampling
+from spiral_amd.core.errors import DimensionError
+from spiral_amd.dtdg.types import Snapshot, VEInvariantDTDG
+
+TARGET = "target"
+LABEL = "label"
+
+
+def get_new_nodes(dgraph: VEInvariantDTDG, t: int) -> np.ndarray:
+    """Ids of the nodes that appear at time index t."""
+    return np.arange(dgraph._node_time_anchors[t - 1], dgraph._node_time_anchors[t])
+
+
+def _successor_table(snapshot: Snapshot) -> Tuple[np.ndarray, np.ndarray]:
+    csr_t = snapshot.observation.csr_t()
+    return csr_t.indptr.cpu().numpy(), csr_t.indices.cpu().numpy()
+
+
+def edge_sample(snapshot: Snapshot, target_node: int, num_positive_edges: int,
+                num_negative_edges: Optional[int] = None, _table=None) -> Tuple[List, List]:
+    """Positive edges (target -> sampled successor) and negative edges (target -> sampled
+    non-neighbour) of one node; empty when it has too few successors."""
+    if num_negative_edges is None:
+        num_negative_edges = num_positive_edges
+    indptr, indices = _table if _table is not None else _successor_table(snapshot)
+    neighbours = indices[indptr[target_node]: indptr[target_node + 1]].astype(np.int64)
+    if len(neighbours) <= num_positive_edges:
+        return [], []
+    pos_inds = np.append(neighbours, target_node)
+    # neg_sampling needs sorted, distinct ids; the reference passes the successor list as it
+    # comes (prepare_dataset.py:47-48), which lets a "negative" coincide with a real
+    # neighbour whenever that list is unsorted.  Sorted here on purpose.
+    neg_sample = neg_sampling(np.unique(pos_inds), snapshot.observation.num_nodes(), num_negative_edges)
+    pos_id = np.random.randint(0, len(pos_inds) - 1, num_positive_edges)
+    pos_sample = neighbours[pos_id]
+    return ([[target_node, int(i)] for i in pos_sample], [[target_node, int(i)] for i in neg_sample])
+
+
+def prepare_edge_task(dgraph: VEInvariantDTDG, num_postive: int, num_negative: Optional[int] = None,
+                      start_t: int = 1, negative_label: int = 0) -> None:
+    """Fill dgraph.time_data['target'|'label'|'positive_edges'][t] for t >= start_t:
+    target = (n_edges, 2) int64 node pairs, positives first; label = 1 / negative_label;
+    positive_edges = ids of the positive edges in the edge table."""
+    dgraph.time_data[TARGET] = {}
+    dgraph.time_data[LABEL] = {}
+    dgraph.time_data["positive_edges"] = {}
+    for t in range(start_t, len(dgraph)):
+        snapshot, _ = dgraph.dispatcher(t)
+        table = _successor_table(snapshot)
+        pos: List = []
+        neg: List = []
+        for n in get_new_nodes(dgraph, t):
+            p, q = edge_sample(snapshot, int(n), num_postive, num_negative, table)
+            pos += p
+            neg += q
+        if len(pos) < 1 or len(neg) < 1:
+            raise DimensionError(f"positive and negative sample has {len(pos)} and {len(neg)} edges")
+        edge_ids = np.array([dgraph.edge_id[f"{e[0]}_{e[1]}"] for e in pos]).astype("int64")
+        dgraph.time_data["positive_edges"][t] = torch.from_numpy(edge_ids)
+        dgraph.time_data[TARGET][t] = torch.from_numpy(np.array(pos + neg).astype("int64"))
+        labels = np.concatenate((np.ones(len(pos)), np.zeros(len(neg)) + float(negative_label)))
+        dgraph.time_data[LABEL][t] = torch.from_numpy(labels)

@@ -128,6 +128,8 @@ class SequentialDecoder(nn.Module):
 
     def forward(self, in_state: Tuple[torch.Tensor, List[int]]):
         node_embs, ids = in_state
+        if isinstance(ids, torch.Tensor) and ids.dim() == 2:
+            return self._forward_edges(node_embs, ids)
         ids_t = None
         if not _is_identity(ids, node_embs.shape[0]) or node_embs.shape[0] > self.n_nodes:
             ids_t = torch.as_tensor(ids, dtype=torch.int64, device=node_embs.device)
@@ -139,6 +141,20 @@ class SequentialDecoder(nn.Module):
                 setattr(self, name, mem.to(node_embs.device))
         out = self._step(node_embs.reshape(-1, self.input_d), ids_t)
         return self.simple_decoder((out.view(-1, self.hidden_d), ids))
+
+    def _forward_edges(self, node_embs: torch.Tensor, pairs: torch.Tensor):
+        """Edge task: `pairs` is (n_edges, 2) node ids.  The recurrent step runs once per
+        distinct node of the pairs (state read and written at those rows), and the simple
+        decoder receives the pairs re-indexed into that list, as the reference's
+        TensorFlow decoders do (tf/sequentialDecoder/baseModel.py:32-46,154-164)."""
+        pairs = pairs.to(node_embs.device)
+        nodes, inverse = torch.unique(pairs.reshape(-1), sorted=True, return_inverse=True)
+        for name in self._memories():
+            mem = getattr(self, name)
+            if mem.device != node_embs.device:
+                setattr(self, name, mem.to(node_embs.device))
+        out = self._step(node_embs.index_select(0, nodes).reshape(-1, self.input_d), nodes)
+        return self.simple_decoder((out.view(-1, self.hidden_d), inverse.reshape(-1, 2)))
 
     def _between_layers(self, x: torch.Tensor, k: int) -> torch.Tensor:
         bm = self.base_model

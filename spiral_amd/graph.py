@@ -296,6 +296,33 @@ class SnapshotGraph(NormalisedAdjacency):
             g.edata[k] = torch.cat([v, pad])
         return g
 
+    def remove_edges(self, eids) -> None:
+        """DGLGraph.remove_edges: drop the edges with the given ids, in place; the ids of the
+        remaining edges are compacted in order (used by the link-prediction loop of
+        examples/tf/link_prediction_sliding_window.py:105-106 to hide the positives)."""
+        eids = torch.as_tensor(eids, dtype=torch.int64, device=self.device).reshape(-1)
+        keep = torch.ones(self._src.numel(), dtype=torch.bool, device=self.device)
+        keep[eids] = False
+        self._src, self._dst = self._src[keep], self._dst[keep]
+        edata = _FrameDict(self._src.numel(), "edges")
+        for k, v in self.edata.items():
+            edata[k] = v[keep]
+        self.edata = edata
+        self._csr = self._csr_t = self._out_deg = None
+        self._norms = {}
+        self._edge_scales = {}
+
+    def successors(self, v: int) -> torch.Tensor:
+        """Destination ids of the edges leaving node v, in edge order."""
+        csr_t = self.csr_t()
+        lo, hi = csr_t.indptr[v: v + 2].tolist()
+        return csr_t.indices[lo:hi].to(torch.int64)
+
+    def predecessors(self, v: int) -> torch.Tensor:
+        csr = self.csr()
+        lo, hi = csr.indptr[v: v + 2].tolist()
+        return csr.indices[lo:hi].to(torch.int64)
+
     # ---- device structures ------------------------------------------------------------
     def csr(self, want_eid: bool = False) -> CSR:
         if self._csr is None or (want_eid and self._csr.eid is None):
