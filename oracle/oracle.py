@@ -236,6 +236,47 @@ def graphconv_torch(src, dst, n, x, weight, bias, norm="both", act=None, slope=0
     return rst
 
 
+def sgconv_torch(src, dst, n, x, weight, bias, k=1):
+    """DGL 0.8 SGConv.forward in differentiable torch ops: k hops of
+    feat*norm -> sum aggregation -> feat*norm with norm = in_degree.clamp(1)^-1/2, then the
+    Linear (weight [out,in]).  Wrapped by the reference's SGCN (staticGraphEncoder.py:135)."""
+    import torch
+
+    src_t = torch.as_tensor(np.asarray(src), dtype=torch.long)
+    dst_t = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+    nrm = torch.bincount(dst_t, minlength=n).float().clamp(min=1).pow(-0.5)[:, None]
+    feat = x
+    for _ in range(k):
+        feat = feat * nrm
+        feat = torch.zeros(n, feat.shape[1], dtype=feat.dtype).index_add_(0, dst_t, feat[src_t])
+        feat = feat * nrm
+    out = feat @ weight.t()
+    return out if bias is None else out + bias
+
+
+def sageconv_gcn_torch(src, dst, n, x, weight, bias, act=None, slope=0.01):
+    """DGL 0.8 SAGEConv.forward, aggregator 'gcn', in differentiable torch ops:
+    h_neigh = (sum of in-neighbours + self) / (in_degree + 1); fc_neigh (weight [out,in], no
+    bias of its own) runs first iff in > out; then + bias, activation."""
+    import torch
+
+    src_t = torch.as_tensor(np.asarray(src), dtype=torch.long)
+    dst_t = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+    before = x.shape[1] > weight.shape[0]
+    h = x @ weight.t() if before else x
+    neigh = torch.zeros(n, h.shape[1], dtype=h.dtype).index_add_(0, dst_t, h[src_t])
+    degs = torch.bincount(dst_t, minlength=n).to(h.dtype)
+    h_neigh = (neigh + h) / (degs[:, None] + 1)
+    if not before:
+        h_neigh = h_neigh @ weight.t()
+    rst = h_neigh if bias is None else h_neigh + bias
+    if act == "relu":
+        rst = torch.relu(rst)
+    elif act == "leaky_relu":
+        rst = torch.nn.functional.leaky_relu(rst, slope)
+    return rst
+
+
 # ----------------------------------------------------------------------------- container
 def is_sorted(a: np.ndarray) -> bool:
     """spiro/core/utils.py:24-33."""

@@ -8,5 +8,8 @@ from torch.nn import Sequential as Sequential
 
 from spiral_amd.core.commonF import nt_layers_list
 from spiral_amd.nn.graphconv import GraphConv
+from spiral_amd.nn.sageconv import SAGEConv
+from spiral_amd.nn.sgconv import SGConv
 
-__all__ = ["Tensor", "Dropout", "MLBaseModel", "Sequential", "nt_layers_list", "GraphConv"]
+__all__ = ["Tensor", "Dropout", "MLBaseModel", "Sequential", "nt_layers_list", "GraphConv", "SGConv",
+           "SAGEConv"]

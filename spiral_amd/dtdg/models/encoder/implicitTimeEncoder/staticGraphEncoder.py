@@ -1,15 +1,15 @@
 """Static graph encoders applied to one snapshot at a time; API of
 spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:35-117.
 
-GCN is the encoder on the accelerated path.  SGCN / GAT / GraphSage of the reference
-sit on other DGL layers and are not provided yet.
+GCN is the encoder on the accelerated path; SGCN and GraphSage ('gcn' aggregator) sit on
+the same aggregation kernel.  GAT (edge softmax) is not provided.
 """
 from abc import abstractmethod
 from typing import List, Tuple
 
 import torch.nn.functional as F
 
-from spiral_amd.core.types import GraphConv, MLBaseModel, Tensor, nt_layers_list
+from spiral_amd.core.types import GraphConv, MLBaseModel, SAGEConv, SGConv, Tensor, nt_layers_list
 from spiral_amd.dtdg.types import Snapshot
 
 
@@ -56,5 +56,37 @@ class GCN(StaticGraphEncoder):
         for layer in self.layers[1:]:
             if training and self.dropout_p > 0:
                 h = F.dropout(h, self.dropout_p, training=True)
+            h = layer(g, h)
+        return (h, dst_node_ids)
+
+
+class SGCN(StaticGraphEncoder):
+    """One SGConv whose hop count k is the number of layers (staticGraphEncoder.py:120-152)."""
+
+    def __init__(self, n_layers: int, in_feats: int, n_hidden: int, **kwargs):
+        super().__init__()
+        self.layers.append(SGConv(in_feats, n_hidden, k=n_layers, **kwargs))
+
+    def forward(self, in_sample: Tuple[Snapshot, List], training: bool = False) -> Tuple[Tensor, List]:
+        snapshot, dst_node_ids = in_sample
+        h = self.layers[0](snapshot.observation, snapshot.node_feature())
+        return (h, dst_node_ids)
+
+
+class GraphSage(StaticGraphEncoder):
+    """`depth` stacked SAGEConv layers (staticGraphEncoder.py:195-225)."""
+
+    def __init__(self, aggregator: str, in_feat: int, n_hidden: int, depth: int = 50, **kwargs):
+        super().__init__()
+        self.depth = depth
+        self.layers.append(SAGEConv(in_feat, n_hidden, aggregator, **kwargs))
+        for _ in range(1, depth):
+            self.layers.append(SAGEConv(n_hidden, n_hidden, aggregator, **kwargs))
+
+    def forward(self, in_sample: Tuple[Snapshot, List], training: bool = False) -> Tuple[Tensor, List]:
+        snapshot, dst_node_ids = in_sample
+        g = snapshot.observation
+        h = snapshot.node_feature()
+        for layer in self.layers:
             h = layer(g, h)
         return (h, dst_node_ids)

@@ -189,9 +189,13 @@ class NormalisedAdjacency:
                    ) -> Optional[torch.Tensor]:
         """Weights w_j in CSR order.  'fwd': by-destination CSR, w_j = norm_out[src_j] for
         norm in ('left','both'); 'bwd': by-source CSR, w_j = norm_in[dst_j] for norm in
-        ('right','both').  A user edge weight (edge-id order) is permuted and multiplied in."""
-        mode = 0 if norm == "both" else 1
-        if direction == "fwd":
+        ('right','both').  norm 'sgc' (SGConv) scales both sides by in-degree^-1/2, so both
+        directions use norm_in.  A user edge weight (edge-id order) is permuted and
+        multiplied in."""
+        mode = 0 if norm in ("both", "sgc") else 1
+        if norm == "sgc":
+            scaled, side = True, "in"
+        elif direction == "fwd":
             scaled, side = norm in ("left", "both"), "out"
         else:
             scaled, side = norm in ("right", "both"), "in"

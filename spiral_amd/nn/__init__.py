@@ -1,3 +1,5 @@
 from .graphconv import GraphConv
+from .sageconv import SAGEConv
+from .sgconv import SGConv
 
-__all__ = ["GraphConv"]
+__all__ = ["GraphConv", "SGConv", "SAGEConv"]

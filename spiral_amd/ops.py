@@ -40,8 +40,8 @@ class GcnAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, g, norm, edge_weight, act, slope):
-        mode = 0 if norm == "both" else 1
-        dst_scale = g.norm("in", mode) if norm in ("right", "both") else None
+        mode = 0 if norm in ("both", "sgc") else 1
+        dst_scale = g.norm("in", mode) if norm in ("right", "both", "sgc") else None
         y = aggregate(g.csr(), x.detach(), None, g.edge_scale("fwd", norm, edge_weight), dst_scale,
                       None if bias is None else bias.detach(), act, slope)
         ctx.g, ctx.norm, ctx.edge_weight, ctx.act, ctx.slope = g, norm, edge_weight, act, slope
@@ -59,8 +59,10 @@ class GcnAggregate(torch.autograd.Function):
         g_x = None
         if need_x:
             g, norm = ctx.g, ctx.norm
-            mode = 0 if norm == "both" else 1
+            mode = 0 if norm in ("both", "sgc") else 1
             out_scale = g.norm("out", mode) if norm in ("left", "both") else None
+            if norm == "sgc":
+                out_scale = g.norm("in", mode)
             g_x = aggregate(g.csr_t(), g_p.contiguous(), None,
                             g.edge_scale("bwd", norm, ctx.edge_weight), out_scale, None, None)
         return g_x, g_b, None, None, None, None, None
@@ -69,7 +71,8 @@ class GcnAggregate(torch.autograd.Function):
 def gcn_aggregate(g, x: torch.Tensor, norm: str = "both", bias: Optional[torch.Tensor] = None,
                   edge_weight: Optional[torch.Tensor] = None, act: Optional[str] = None,
                   slope: float = 0.01) -> torch.Tensor:
-    """Differentiable fused aggregation over graph `g` with DGL GraphConv's `norm` modes."""
+    """Differentiable fused aggregation over graph `g` with DGL GraphConv's `norm` modes
+    ('none', 'both', 'left', 'right') plus 'sgc' (SGConv: in-degree^-1/2 on both sides)."""
     if edge_weight is not None and edge_weight.requires_grad:
         raise nv.SpmiError("gradients with respect to edge_weight are not implemented")
     return GcnAggregate.apply(x, bias, g, norm, edge_weight, act, slope)

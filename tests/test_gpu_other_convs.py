@@ -1,0 +1,91 @@
+"""SGConv and SAGEConv('gcn') on the GPU against torch restatements of DGL 0.8's layers
+(parity unpinned by the reference: DGL is absent and it holds no fixture).  fp32, 1e-5
+relative to the largest magnitude for outputs and gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as orc
+from spiral_amd.core.errors import GraphError
+from spiral_amd.core.types import SAGEConv, SGConv
+from spiral_amd.dtdg.models.encoder.implicitTimeEncoder.staticGraphEncoder import SGCN, GraphSage
+from spiral_amd.dtdg.types import Snapshot
+from spiral_amd.graph import SnapshotGraph
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _graph(dev, n=800, e=7000, seed=0):
+    src, dst = orc.powerlaw_snapshot(n, e, t=seed)
+    return src, dst, SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+
+
+@pytest.mark.parametrize("fi,fo,k", [(16, 8, 1), (16, 16, 2), (12, 32, 3)])
+def test_sgconv(dev, fi, fo, k):
+    n = 800
+    src, dst, g = _graph(dev, n, seed=k)
+    torch.manual_seed(k)
+    conv = SGConv(fi, fo, k=k, allow_zero_in_degree=True).to(dev)
+    with torch.no_grad():
+        conv.fc.bias.normal_()
+    x = torch.randn(n, fi)
+    xr = x.clone().requires_grad_()
+    w = conv.fc.weight.detach().cpu().clone().requires_grad_()
+    b = conv.fc.bias.detach().cpu().clone().requires_grad_()
+    y_ref = orc.sgconv_torch(src, dst, n, xr, w, b, k)
+    y_ref.pow(2).sum().backward()
+    xg = x.to(dev).requires_grad_()
+    y = conv(g, xg)
+    y.pow(2).sum().backward()
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel(conv.fc.weight.grad.cpu(), w.grad) < 1e-5
+    assert rel(conv.fc.bias.grad.cpu(), b.grad) < 1e-5
+    with pytest.raises(GraphError):
+        SGConv(fi, fo).to(dev)(g, xg)
+
+
+@pytest.mark.parametrize("fi,fo,act", [(16, 8, "leaky_relu"), (16, 16, None), (12, 32, "relu")])
+def test_sageconv_gcn(dev, fi, fo, act):
+    n = 800
+    src, dst, g = _graph(dev, n, seed=fi + fo)
+    torch.manual_seed(fo)
+    fn = {"leaky_relu": F.leaky_relu, "relu": F.relu, None: None}[act]
+    conv = SAGEConv(fi, fo, "gcn", activation=fn).to(dev)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, fi)
+    xr = x.clone().requires_grad_()
+    w = conv.fc_neigh.weight.detach().cpu().clone().requires_grad_()
+    b = conv.bias.detach().cpu().clone().requires_grad_()
+    y_ref = orc.sageconv_gcn_torch(src, dst, n, xr, w, b, act)
+    y_ref.pow(2).sum().backward()
+    xg = x.to(dev).requires_grad_()
+    y = conv(g, xg)
+    y.pow(2).sum().backward()
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel(conv.fc_neigh.weight.grad.cpu(), w.grad) < 1e-5
+    assert rel(conv.bias.grad.cpu(), b.grad) < 1e-5
+    with pytest.raises(NotImplementedError):
+        SAGEConv(fi, fo, "mean")
+    with pytest.raises(GraphError):
+        SAGEConv(fi, fo, "sum")
+
+
+def test_encoders_run(dev):
+    n = 500
+    src, dst, g = _graph(dev, n, 4000, seed=9)
+    g.ndata["h"] = torch.randn(n, 12, device=dev)
+    snap = Snapshot(g, 0)
+    ids = torch.arange(n)
+    h, out_ids = SGCN(2, 12, 16, allow_zero_in_degree=True).to(dev)((snap, ids))
+    assert h.shape == (n, 16) and out_ids is ids
+    h, _ = GraphSage("gcn", 12, 16, depth=3, activation=F.leaky_relu).to(dev)((snap, ids))
+    assert h.shape == (n, 16) and torch.isfinite(h).all()
