@@ -43,6 +43,10 @@ extern "C" {
 #define SPMI_ACT_RELU 1
 #define SPMI_ACT_LEAKY_RELU 2 /* slope given separately (torch default 0.01) */
 
+/* storage type of feature rows (sums are always float32) */
+#define SPMI_DTYPE_F32 0
+#define SPMI_DTYPE_BF16 1
+
 /* degree -> norm modes (DGL GraphConv `norm`) */
 #define SPMI_NORM_RSQRT 0 /* clamp(deg,1)^-0.5 : norm='both'            */
 #define SPMI_NORM_RECIP 1 /* 1/clamp(deg,1)    : norm='right' / 'left'  */
@@ -130,6 +134,18 @@ int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
                   const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr,
                   int32_t n_heavy, int32_t n_chunks, int32_t heavy_thresh, int32_t chunk,
                   float* partial_ws /*device [n_chunks*F]*/, void* stream);
+
+/* Same aggregation with feature rows stored as float32 or bfloat16 (x_dtype / y_dtype =
+ * SPMI_DTYPE_*; leading dimensions in elements).  Every product and sum is float32; a
+ * bfloat16 output is rounded once, at the store.  The reference has no reduced-precision
+ * path: this serves bf16 feature storage (half the gather bytes per edge). */
+int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                     int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
+                     const float* src_scale, const float* edge_w, const float* dst_scale,
+                     const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
+                     const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
+                     int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
+                     void* stream);
 
 /* ------------------------------------------------------------------------
  * Backward of the fused epilogue: gP = gY * act'(Y) and gb = column sums.

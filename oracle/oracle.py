@@ -277,6 +277,28 @@ def sageconv_gcn_torch(src, dst, n, x, weight, bias, act=None, slope=0.01):
     return rst
 
 
+def evolve_gcn_o_torch(snapshots, n, x, init_weights, grus, biases, act="leaky_relu",
+                       detach_state=True):
+    """EvolveGCN-O over a list of snapshots [(src, dst), ...] in differentiable torch ops.
+    Per snapshot and layer: W_t = GRU(input=W_{t-1}, h0=W_{t-1}) with rows as batch
+    (`grus[l]` is a torch.nn.GRU(cols, cols, batch_first=True)), then GraphConv with the
+    external weight W_t (graphconv_torch).  Not in the reference; this IS the definition
+    the GPU path is held to.  Returns the list of per-snapshot outputs."""
+    state = list(init_weights)
+    outs = []
+    for src, dst in snapshots:
+        new = []
+        for w, gru in zip(state, grus):
+            o, _ = gru(w[:, None, :], w[None].contiguous())
+            new.append(o[:, 0, :])
+        h = x
+        for w, b in zip(new, biases):
+            h = graphconv_torch(src, dst, n, h, w, b, act=act)
+        outs.append(h)
+        state = [w.detach() for w in new] if detach_state else new
+    return outs
+
+
 # ----------------------------------------------------------------------------- container
 def is_sorted(a: np.ndarray) -> bool:
     """spiro/core/utils.py:24-33."""

@@ -44,16 +44,42 @@ struct VecOf<4> {
   using type = float __attribute__((ext_vector_type(4)));
 };
 
+// Feature rows are stored as float32 or bfloat16; sums are always float32.
+template <int VEC, typename T>
+__device__ __forceinline__ typename VecOf<VEC>::type load_row(const T* p) {
+  using V = typename VecOf<VEC>::type;
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const V*>(p);
+  } else if constexpr (VEC == 1) {
+    return static_cast<float>(*p);
+  } else {
+    using B = __bf16 __attribute__((ext_vector_type(VEC)));
+    return __builtin_convertvector(*reinterpret_cast<const B*>(p), V);
+  }
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void store_row(T* p, typename VecOf<VEC>::type v) {
+  using V = typename VecOf<VEC>::type;
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<V*>(p) = v;
+  } else if constexpr (VEC == 1) {
+    *p = static_cast<T>(v);
+  } else {
+    using B = __bf16 __attribute__((ext_vector_type(VEC)));
+    *reinterpret_cast<B*>(p) = __builtin_convertvector(v, B);
+  }
+}
+
 struct SpmmParams {
   const int32_t* indptr;
   const int32_t* indices;
-  const float* X;
+  const void* X;
   const float* src_scale;
   const float* edge_w;
   const float* dst_scale;
   const float* bias;
-  float* Y;
-  int64_t ldx, ldy;
+  void* Y;
+  int64_t ldx, ldy;  // in elements
   int32_t n_rows;
   int32_t F;
   int32_t rows_per_wave;
@@ -84,8 +110,8 @@ __device__ __forceinline__ typename VecOf<VEC>::type activate(typename VecOf<VEC
 // Sum of w_j * X[indices[j]] over the CSR range [s,e) as seen by one wave, with a
 // callback at every row boundary.  `row_end_of(row)` returns indptr of row+1 and
 // `flush(row, acc)` consumes a finished row; both are wave-uniform.
-template <int VEC, typename RowEnd, typename Flush>
-__device__ __forceinline__ void stream_range(const SpmmParams& p, const float* __restrict__ xcol,
+template <int VEC, typename XT, typename RowEnd, typename Flush>
+__device__ __forceinline__ void stream_range(const SpmmParams& p, const XT* __restrict__ xcol,
                                              bool fok, int lane, int s, int e, int row,
                                              int row_last, RowEnd row_end_of, Flush flush) {
   using V = typename VecOf<VEC>::type;
@@ -110,7 +136,7 @@ __device__ __forceinline__ void stream_range(const SpmmParams& p, const float* _
         const int src = readlane_i(my, kk);
         wk[u] = weighted ? readlane_f(w, kk) : 1.0f;
         v[u] = V(0.0f);
-        if (fok) v[u] = *reinterpret_cast<const V*>(xcol + static_cast<int64_t>(src) * p.ldx);
+        if (fok) v[u] = load_row<VEC, XT>(xcol + static_cast<int64_t>(src) * p.ldx);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -134,7 +160,7 @@ __device__ __forceinline__ void stream_range(const SpmmParams& p, const float* _
   }
 }
 
-template <int VEC>
+template <int VEC, typename XT, typename YT>
 __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
   using V = typename VecOf<VEC>::type;
   const int lane = threadIdx.x & 63;
@@ -158,30 +184,30 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
   const bool heavy_lane = (lane < nr) && (ip_next - ip > p.heavy_thresh);
   const bool any_heavy = __ballot(heavy_lane) != 0ull;
 
-  const float* xcol = p.X + f;
-  float* ycol = p.Y + f;
+  const XT* xcol = static_cast<const XT*>(p.X) + f;
+  YT* ycol = static_cast<YT*>(p.Y) + f;
   auto row_end_of = [&](int row) { return readlane_i(ip, row + 1); };
   auto flush = [&](int row, V acc) {
     const float ds = readlane_f(dsl, row);
     V y = activate<VEC>(acc * ds + bias, p.act, p.slope);
-    if (fok) *reinterpret_cast<V*>(ycol + static_cast<int64_t>(r0 + row) * p.ldy) = y;
+    if (fok) store_row<VEC, YT>(ycol + static_cast<int64_t>(r0 + row) * p.ldy, y);
   };
 
   if (!any_heavy) {
-    stream_range<VEC>(p, xcol, fok, lane, readlane_i(ip, 0), readlane_i(ip, nr), 0, nr - 1,
-                      row_end_of, flush);
+    stream_range<VEC, XT>(p, xcol, fok, lane, readlane_i(ip, 0), readlane_i(ip, nr), 0, nr - 1,
+                          row_end_of, flush);
   } else {
     for (int row = 0; row < nr; ++row) {
       const int rs = readlane_i(ip, row), re = readlane_i(ip, row + 1);
       if (re - rs > p.heavy_thresh) continue;  // summed by the heavy-row kernels
-      stream_range<VEC>(p, xcol, fok, lane, rs, re, row, row, row_end_of, flush);
+      stream_range<VEC, XT>(p, xcol, fok, lane, rs, re, row, row, row_end_of, flush);
     }
   }
 }
 
 // One workgroup sums one chunk of a heavy row; its four waves take a quarter of
 // the chunk each and are combined through LDS in wave order.
-template <int VEC>
+template <int VEC, typename XT>
 __global__ __launch_bounds__(kThreads) void spmm_heavy_kernel(SpmmParams p,
                                                               const int32_t* __restrict__ heavy_rows,
                                                               const int32_t* __restrict__ chunk_ptr,
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void spmm_heavy_kernel(SpmmParams p,
   V total = V(0.0f);
   auto row_end_of = [&](int) { return INT_MAX; };
   auto flush = [&](int, V acc) { total = acc; };
-  stream_range<VEC>(p, p.X + f, fok, lane, s, e, 0, 0, row_end_of, flush);
+  stream_range<VEC, XT>(p, static_cast<const XT*>(p.X) + f, fok, lane, s, e, 0, 0, row_end_of, flush);
   s_part[wave][lane] = total;
   __syncthreads();
   if (wave == 0 && fok) {
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void spmm_heavy_kernel(SpmmParams p,
 // One workgroup finishes one heavy row: partial sums are added in a fixed order
 // (wave w takes chunks w, w+4, ...; waves combined in wave order), then the
 // same epilogue as the stream kernel.
-template <int VEC>
+template <int VEC, typename YT>
 __global__ __launch_bounds__(kThreads) void spmm_heavy_reduce_kernel(
     SpmmParams p, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ chunk_ptr,
     const float* __restrict__ partial) {
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void spmm_heavy_reduce_kernel(
     V bias = V(0.0f);
     if (p.bias) bias = *reinterpret_cast<const V*>(p.bias + f);
     V y = activate<VEC>(sum * ds + bias, p.act, p.slope);
-    *reinterpret_cast<V*>(p.Y + static_cast<int64_t>(row) * p.ldy + f) = y;
+    store_row<VEC, YT>(static_cast<YT*>(p.Y) + static_cast<int64_t>(row) * p.ldy + f, y);
   }
 }
 
@@ -306,35 +332,58 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <int VEC>
+template <int VEC, typename XT, typename YT>
 int launch_spmm(const SpmmParams& p, const int32_t* heavy_rows, const int32_t* chunk_ptr,
                 int n_heavy, int n_chunks, int chunk, float* partial, hipStream_t st) {
   const unsigned fblocks = static_cast<unsigned>((p.F + 64 * VEC - 1) / (64 * VEC));
   const int64_t n_waves = (static_cast<int64_t>(p.n_rows) + p.rows_per_wave - 1) / p.rows_per_wave;
   const unsigned grid_x = static_cast<unsigned>((n_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  spmm_stream_kernel<VEC><<<dim3(grid_x, fblocks), kThreads, 0, st>>>(p);
+  spmm_stream_kernel<VEC, XT, YT><<<dim3(grid_x, fblocks), kThreads, 0, st>>>(p);
   SPMI_CHECK_LAUNCH("spmm_stream");
   if (n_heavy > 0) {
-    spmm_heavy_kernel<VEC><<<dim3(n_chunks, fblocks), kThreads, 0, st>>>(p, heavy_rows, chunk_ptr,
-                                                                        n_heavy, chunk, partial);
+    spmm_heavy_kernel<VEC, XT><<<dim3(n_chunks, fblocks), kThreads, 0, st>>>(
+        p, heavy_rows, chunk_ptr, n_heavy, chunk, partial);
     SPMI_CHECK_LAUNCH("spmm_heavy");
-    spmm_heavy_reduce_kernel<VEC><<<dim3(n_heavy, fblocks), kThreads, 0, st>>>(p, heavy_rows,
-                                                                              chunk_ptr, partial);
+    spmm_heavy_reduce_kernel<VEC, YT><<<dim3(n_heavy, fblocks), kThreads, 0, st>>>(
+        p, heavy_rows, chunk_ptr, partial);
     SPMI_CHECK_LAUNCH("spmm_heavy_reduce");
   }
   return SPMI_OK;
+}
+
+
+template <typename XT, typename YT>
+int dispatch_spmm(SpmmParams& p, const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr,
+                  int32_t n_heavy, int32_t n_chunks, int32_t chunk, float* partial_ws,
+                  hipStream_t st) {
+  // widest per-lane access whose alignment holds for both the input and the output rows
+  auto ok = [&](int vec) {
+    const size_t ax = vec * sizeof(XT), ay = vec * sizeof(YT);
+    return p.F % vec == 0 && p.ldx % vec == 0 && p.ldy % vec == 0 && aligned(p.X, ax) &&
+           aligned(p.Y, ay) && (!p.bias || aligned(p.bias, vec * 4)) &&
+           (!partial_ws || aligned(partial_ws, vec * 4));
+  };
+  if (p.F >= 256 && ok(4))
+    return launch_spmm<4, XT, YT>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                  partial_ws, st);
+  if (p.F >= 128 && ok(2))
+    return launch_spmm<2, XT, YT>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                  partial_ws, st);
+  return launch_spmm<1, XT, YT>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                partial_ws, st);
 }
 
 }  // namespace
 
 extern "C" {
 
-int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
-                  int64_t E, const float* X, int64_t ldx, int64_t F, const float* src_scale,
-                  const float* edge_w, const float* dst_scale, const float* bias, int act,
-                  float slope, float* Y, int64_t ldy, const int32_t* heavy_rows,
-                  const int32_t* heavy_chunk_ptr, int32_t n_heavy, int32_t n_chunks,
-                  int32_t heavy_thresh, int32_t chunk, float* partial_ws, void* stream) {
+int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                     int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
+                     const float* src_scale, const float* edge_w, const float* dst_scale,
+                     const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
+                     const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
+                     int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
+                     void* stream) {
   SPMI_REQUIRE(n_rows >= 0 && n_src >= 0 && E >= 0 && F >= 1, SPMI_ERR_INVALID_ARG,
                "spmi_gcn_spmm: bad sizes n_rows=%lld n_src=%lld E=%lld F=%lld", (long long)n_rows,
                (long long)n_src, (long long)E, (long long)F);
@@ -343,6 +392,9 @@ int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
                SPMI_ERR_UNSUPPORTED, "spmi_gcn_spmm: size beyond the int32 on-device limits");
   SPMI_REQUIRE(act >= SPMI_ACT_NONE && act <= SPMI_ACT_LEAKY_RELU, SPMI_ERR_INVALID_ARG,
                "spmi_gcn_spmm: bad activation code %d", act);
+  SPMI_REQUIRE((x_dtype == SPMI_DTYPE_F32 || x_dtype == SPMI_DTYPE_BF16) &&
+                   (y_dtype == SPMI_DTYPE_F32 || y_dtype == SPMI_DTYPE_BF16),
+               SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: bad dtype code (%d, %d)", x_dtype, y_dtype);
   if (n_rows == 0) return SPMI_OK;
   SPMI_REQUIRE(indptr && Y, SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: null indptr/Y");
   SPMI_REQUIRE(E == 0 || (indices && X), SPMI_ERR_INVALID_ARG, "spmi_gcn_spmm: null indices/X");
@@ -379,17 +431,29 @@ int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
   p.rows_per_wave = rpw;
 
   hipStream_t st = spmi::as_stream(stream);
-  const bool a16 = aligned(X, 16) && aligned(Y, 16) && (!bias || aligned(bias, 16)) &&
-                   (!partial_ws || aligned(partial_ws, 16)) && ldx % 4 == 0 && ldy % 4 == 0 &&
-                   F % 4 == 0;
-  const bool a8 = aligned(X, 8) && aligned(Y, 8) && (!bias || aligned(bias, 8)) &&
-                  (!partial_ws || aligned(partial_ws, 8)) && ldx % 2 == 0 && ldy % 2 == 0 &&
-                  F % 2 == 0;
-  if (F >= 256 && a16)
-    return launch_spmm<4>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
-  if (F >= 128 && a8)
-    return launch_spmm<2>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
-  return launch_spmm<1>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk, partial_ws, st);
+  if (x_dtype == SPMI_DTYPE_F32 && y_dtype == SPMI_DTYPE_F32)
+    return dispatch_spmm<float, float>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                       partial_ws, st);
+  if (x_dtype == SPMI_DTYPE_BF16 && y_dtype == SPMI_DTYPE_BF16)
+    return dispatch_spmm<__bf16, __bf16>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                         partial_ws, st);
+  if (x_dtype == SPMI_DTYPE_BF16)
+    return dispatch_spmm<__bf16, float>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                        partial_ws, st);
+  return dispatch_spmm<float, __bf16>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
+                                      partial_ws, st);
+}
+
+int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                  int64_t E, const float* X, int64_t ldx, int64_t F, const float* src_scale,
+                  const float* edge_w, const float* dst_scale, const float* bias, int act,
+                  float slope, float* Y, int64_t ldy, const int32_t* heavy_rows,
+                  const int32_t* heavy_chunk_ptr, int32_t n_heavy, int32_t n_chunks,
+                  int32_t heavy_thresh, int32_t chunk, float* partial_ws, void* stream) {
+  return spmi_gcn_spmm_ex(indptr, indices, n_rows, n_src, E, X, SPMI_DTYPE_F32, ldx, F, src_scale,
+                          edge_w, dst_scale, bias, act, slope, Y, SPMI_DTYPE_F32, ldy, heavy_rows,
+                          heavy_chunk_ptr, n_heavy, n_chunks, heavy_thresh, chunk, partial_ws,
+                          stream);
 }
 
 int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,

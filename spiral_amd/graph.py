@@ -27,6 +27,7 @@ HEAVY_THRESH = 512  # rows with more nonzeros than this are summed chunk-wise by
 HEAVY_CHUNK = 256   # nonzeros per chunk (one workgroup, four waves of 64)
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
+_DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}
 
 # Optional launch timing of the aggregation (bench.py): when a list is installed, every
 # call of `aggregate` appends (start_event, end_event, nnz, n_rows, F) recorded on the
@@ -136,13 +137,16 @@ def degree(ids: torch.Tensor, n: int) -> torch.Tensor:
 def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = None,
               edge_w: Optional[torch.Tensor] = None, dst_scale: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
-              slope: float = 0.01, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              slope: float = 0.01, out: Optional[torch.Tensor] = None,
+              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Y = act(dst_scale * (A (src_scale * X) with edge weights) + bias), one fused launch
-    (plus two for hub rows).  No autograd here; see ops.GcnAggregate."""
+    (plus two for hub rows).  X and Y are stored as float32 or bfloat16 (sums are float32;
+    Y defaults to X's type); scales and bias are float32.  No autograd here; see
+    ops.GcnAggregate."""
     nv.require_cuda(x, src_scale, edge_w, dst_scale, bias, out)
-    if x.dim() != 2 or x.dtype != torch.float32:
-        raise nv.SpmiError(f"aggregate expects a 2-D float32 feature matrix, got {tuple(x.shape)} "
-                           f"{x.dtype}")
+    if x.dim() != 2 or x.dtype not in _DTYPE_CODES:
+        raise nv.SpmiError(f"aggregate expects a 2-D float32/bfloat16 feature matrix, got "
+                           f"{tuple(x.shape)} {x.dtype}")
     if x.shape[0] != csr.n_cols:
         raise nv.SpmiError(f"feature matrix has {x.shape[0]} rows, the graph addresses {csr.n_cols}")
     if x.stride(1) != 1:
@@ -153,20 +157,21 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
         if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous()):
             raise nv.SpmiError(f"{name} must be contiguous float32 with {n} elements")
     if out is None:
-        out = torch.empty(csr.n_rows, feat, dtype=torch.float32, device=x.device)
-    elif out.shape != (csr.n_rows, feat) or out.dtype != torch.float32 or out.stride(1) != 1:
+        out = torch.empty(csr.n_rows, feat, dtype=out_dtype or x.dtype, device=x.device)
+    elif out.shape != (csr.n_rows, feat) or out.dtype not in _DTYPE_CODES or out.stride(1) != 1:
         raise nv.SpmiError("bad `out` tensor")
     with torch.cuda.device(x.device):
         partial = csr.partial_ws(feat)
         if _launch_log is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        nv.check(nv.lib().spmi_gcn_spmm(
+        nv.check(nv.lib().spmi_gcn_spmm_ex(
             nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.n_cols, csr.nnz,
-            nv.ptr(x), x.stride(0), feat, nv.ptr(src_scale), nv.ptr(edge_w), nv.ptr(dst_scale),
-            nv.ptr(bias), _ACT_CODES[act], float(slope), nv.ptr(out), out.stride(0),
-            nv.ptr(csr.heavy_rows), nv.ptr(csr.heavy_chunk_ptr), csr.n_heavy, csr.n_chunks,
-            csr.heavy_thresh, csr.chunk, nv.ptr(partial), nv.stream()), "spmi_gcn_spmm")
+            nv.ptr(x), _DTYPE_CODES[x.dtype], x.stride(0), feat, nv.ptr(src_scale), nv.ptr(edge_w),
+            nv.ptr(dst_scale), nv.ptr(bias), _ACT_CODES[act], float(slope), nv.ptr(out),
+            _DTYPE_CODES[out.dtype], out.stride(0), nv.ptr(csr.heavy_rows),
+            nv.ptr(csr.heavy_chunk_ptr), csr.n_heavy, csr.n_chunks, csr.heavy_thresh, csr.chunk,
+            nv.ptr(partial), nv.stream()), "spmi_gcn_spmm_ex")
         if _launch_log is not None:
             ev1.record()
             _launch_log.append((ev0, ev1, csr.nnz, csr.n_rows, feat))

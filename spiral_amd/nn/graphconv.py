@@ -88,16 +88,19 @@ class GraphConv(nn.Module):
 
         code, slope, unfused = _classify_activation(self._activation)
 
+        if weight is not None and weight.dtype != feat.dtype:
+            weight = weight.to(feat.dtype)  # bf16 feature storage: the projection runs in bf16
         if self._in_feats >= self._out_feats:
             if weight is not None:
                 feat = feat @ weight
             rst = gcn_aggregate(graph, feat, self._norm, self.bias, edge_weight, code, slope)
         else:
             rst = gcn_aggregate(graph, feat, self._norm, None, edge_weight, None)
+            bias = None if self.bias is None else self.bias.to(rst.dtype)
             if weight is not None:
-                rst = torch.addmm(self.bias, rst, weight) if self.bias is not None else rst @ weight
-            elif self.bias is not None:
-                rst = rst + self.bias
+                rst = torch.addmm(bias, rst, weight) if bias is not None else rst @ weight
+            elif bias is not None:
+                rst = rst + bias
             if code == "relu":
                 rst = F.relu(rst)
             elif code == "leaky_relu":

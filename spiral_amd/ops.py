@@ -18,6 +18,13 @@ from .graph import aggregate
 def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope: float,
                   want_gb: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """gP = gY * act'(Y) and gb = column sums of gP, one pass."""
+    if g_y.dtype != torch.float32:  # bf16 storage: elementwise torch ops, fp32 column sums
+        g_p = g_y
+        if act == "relu":
+            g_p = torch.where(y > 0, g_y, torch.zeros_like(g_y))
+        elif act == "leaky_relu":
+            g_p = torch.where(y > 0, g_y, g_y * slope)
+        return g_p, (g_p.sum(0, dtype=torch.float32) if want_gb else None)
     m, f = g_y.shape
     if g_y.stride(1) != 1 or g_y.stride(0) != y.stride(0):
         g_y = g_y.contiguous()
@@ -253,6 +260,60 @@ class RnnCell(torch.autograd.Function):
         g_whh = g_g.t() @ h_old if ctx.needs_input_grad[2] else None
         g_b = g_g.sum(0) if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         return g_x, g_wih, g_whh, g_b, g_b, None, None, None
+
+
+class GruCellDense(torch.autograd.Function):
+    """GRU step with the previous state as an ordinary differentiable tensor (no node
+    memory): used where the recurrent state is itself a trained quantity, e.g. a weight
+    matrix that evolves over snapshots."""
+
+    @staticmethod
+    def forward(ctx, x, h, w_ih, w_hh, b_ih, b_hh):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd, hdn = x.detach().contiguous(), h.detach().contiguous()
+        saved = torch.empty(m, 5 * hd, dtype=torch.float32, device=x.device)
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        if _fused_ok(xd, w_hh):
+            _fused_cell("gru", xd, w_ih, w_hh, b_ih, b_hh, hdn, None, None, False, h_out, None, saved)
+        else:
+            gi = xd @ w_ih.detach().t()
+            gh = hdn @ w_hh.detach().t()
+            with torch.cuda.device(x.device):
+                nv.check(nv.lib().spmi_gru_gate_fwd(
+                    nv.ptr(gi), nv.ptr(gh), nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(hdn), None, m, hd,
+                    nv.ptr(h_out), 0, nv.ptr(saved), nv.stream()), "spmi_gru_gate_fwd")
+        ctx.save_for_backward(xd, w_ih, w_hh, saved)
+        ctx.has_bias = b_ih is not None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xd, w_ih, w_hh, saved = ctx.saved_tensors
+        m, hd = g_out.shape
+        g_out = g_out.contiguous()
+        g_gi = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_out.device)
+        g_gh = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_out.device)
+        g_hd = torch.empty(m, hd, dtype=torch.float32, device=g_out.device)
+        with torch.cuda.device(g_out.device):
+            nv.check(nv.lib().spmi_gru_gate_bwd(nv.ptr(g_out), nv.ptr(saved), m, hd, nv.ptr(g_gi),
+                                                nv.ptr(g_gh), nv.ptr(g_hd), nv.stream()),
+                     "spmi_gru_gate_bwd")
+        h_old = saved[:, 4 * hd:]
+        g_x = g_gi @ w_ih if ctx.needs_input_grad[0] else None
+        g_h = g_hd + g_gh @ w_hh if ctx.needs_input_grad[1] else None
+        g_wih = g_gi.t() @ xd if ctx.needs_input_grad[2] else None
+        g_whh = g_gh.t() @ h_old if ctx.needs_input_grad[3] else None
+        g_bih = g_gi.sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        g_bhh = g_gh.sum(0) if ctx.has_bias and ctx.needs_input_grad[5] else None
+        return g_x, g_h, g_wih, g_whh, g_bih, g_bhh
+
+
+def gru_cell_dense(x, h, w_ih, w_hh, b_ih=None, b_hh=None):
+    """h' = GRU(x, h) for dense [M, I] / [M, H] float32 CUDA tensors, differentiable in both."""
+    nv.require_cuda(x, h)
+    if x.dtype != torch.float32 or h.dtype != torch.float32:
+        raise nv.SpmiError("recurrent cells compute in float32")
+    return GruCellDense.apply(x, h, w_ih, w_hh, b_ih, b_hh)
 
 
 def gru_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):

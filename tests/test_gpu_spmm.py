@@ -93,3 +93,31 @@ def test_repeatable(dev):
     a = G.aggregate(csr, x)
     b = G.aggregate(csr, x)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("f,out_bf16", [(128, True), (128, False), (256, True), (64, True), (130, True)])
+def test_bf16_feature_storage(dev, f, out_bf16):
+    """bf16 rows in, fp32 sums.  Documented bf16 tolerance: the oracle runs on the same
+    bf16-rounded inputs (exact in fp32), so an fp32 output must agree to the usual 1e-5 and a
+    bf16 output to half a bf16 ulp of the value (2^-9 relative) plus that 1e-5."""
+    n, e = 6000, 150_000
+    rng = np.random.default_rng(f)
+    src, dst = orc.powerlaw_snapshot(n, e, t=f, k_dst=5.0)
+    xb = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(torch.bfloat16)
+    x = xb.to(torch.float32).numpy()
+    indptr, indices, _ = orc.coo_to_csr(dst, src, n)
+    ss = orc.norm_from_indptr(orc.coo_to_csr(src, dst, n)[0])
+    ds = orc.norm_from_indptr(indptr)
+    b = rng.standard_normal(f).astype(np.float32)
+    want = orc.aggregate(indptr, indices, x, ss, None, ds, b, "leaky_relu", 0.01)
+    scale = orc.aggregate(indptr, indices, np.abs(x), ss, None, ds, np.abs(b)) + 1e-30
+    csr = G.build_csr(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n, n,
+                      heavy_thresh=256, chunk=128)
+    assert csr.n_heavy > 0
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got = G.aggregate(csr, xb.to(dev), t(ss), None, t(ds), t(b), "leaky_relu", 0.01,
+                      out_dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    assert got.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    err = np.abs(got.float().cpu().numpy() - want)
+    bound = RTOL * scale + (2.0 ** -8) * np.abs(want) * out_bf16
+    assert (err <= bound).all(), f"worst excess {(err - bound).max():.3e}"
