@@ -66,6 +66,14 @@ WORKLOADS = {
     "config3": dict(n=10_000_000, e=100_000_000, f=128, hidden=128, rnn_hidden=128, snapshots=4,
                     k_dst=3.0, k_src=1.5,
                     name="synthetic power-law DTDG, 10M nodes x 100M edges/snapshot (BASELINE configs[2] size)"),
+    "config4": dict(n=1_000_000, e=10_000_000, f=128, hidden=128, rnn_hidden=0, snapshots=32,
+                    k_dst=3.0, k_src=1.5, model="evolve_bf16",
+                    name="EvolveGCN-O (weight GRU per snapshot), bf16 feature storage, 1M nodes x 10M "
+                         "edges/snapshot (BASELINE configs[3]; 32 resident snapshots cycled)"),
+    "config5": dict(n=1_000_000, e=10_000_000, f=256, hidden=512, rnn_hidden=512, snapshots=8,
+                    k_dst=6.0, k_src=1.5,
+                    name="wide-feature stress: 256-d features, 512-d hidden, heavy degree skew "
+                         "(k_dst=6), per-GPU size of BASELINE configs[4]"),
     "small": dict(n=50_000, e=500_000, f=128, hidden=128, rnn_hidden=128, snapshots=4,
                   k_dst=3.0, k_src=1.5, name="small smoke workload"),
 }
@@ -83,20 +91,30 @@ def gen_snapshot(n, e, t, k_dst, k_src, perm, dev):
     return src, dst
 
 
-def algorithmic_bytes(e, n_rows, f):
-    return e * (f * 4 + 4) + (n_rows + 1) * 4 + 2 * n_rows * 4 + n_rows * f * 4 + f * 4
+def algorithmic_bytes(e, n_rows, f, s=4):
+    """Gather model of one fused aggregation launch; s = bytes per stored feature."""
+    return e * (f * s + 4) + (n_rows + 1) * 4 + 2 * n_rows * 4 + n_rows * f * s + f * 4
 
 
 class Path(torch.nn.Module):
     """The modules of the hot path, built from the package's own layers."""
 
-    def __init__(self, f, hidden, rnn_hidden, n_local, dev):
+    def __init__(self, f, hidden, rnn_hidden, n_local, dev, kind="gcn_gru"):
         super().__init__()
-        self.conv1 = GraphConv(f, hidden, activation=F.leaky_relu, allow_zero_in_degree=True)
-        self.conv2 = GraphConv(hidden, hidden, activation=F.leaky_relu, allow_zero_in_degree=True)
-        self.rnn = GRU(hidden, rnn_hidden, n_local, 2, MLP(rnn_hidden, [10, 20, 10, 5]))
+        self.kind = kind
+        if kind == "evolve_bf16":
+            from spiral_amd.nn.evolve import EvolveGCNO
+
+            self.encoder = EvolveGCNO(2, f, hidden, activation=F.leaky_relu, allow_zero_in_degree=True,
+                                      storage_dtype=torch.bfloat16)
+            self.rnn = None
+        else:
+            self.conv1 = GraphConv(f, hidden, activation=F.leaky_relu, allow_zero_in_degree=True)
+            self.conv2 = GraphConv(hidden, hidden, activation=F.leaky_relu, allow_zero_in_degree=True)
+            self.rnn = GRU(hidden, rnn_hidden, n_local, 2, MLP(rnn_hidden, [10, 20, 10, 5]))
         self.to(dev)
-        self.rnn.to(dev)
+        if self.rnn is not None:
+            self.rnn.to(dev)
         self.eval()  # MLP: BatchNorm running statistics, no dropout (inference pass)
 
 
@@ -195,7 +213,12 @@ def main():
     gen.manual_seed(7)
     x_local = torch.randn(n_local, f, generator=gen, device=dev)
     torch.manual_seed(11)
-    model = Path(f, w["hidden"], w["rnn_hidden"], n_local, dev)
+    kind = w.get("model", "gcn_gru")
+    if kind != "gcn_gru" and world > 1:
+        raise SystemExit(f"workload {args.workload} is single-GPU in this bench")
+    model = Path(f, w["hidden"], w["rnn_hidden"], n_local, dev, kind)
+    if kind == "evolve_bf16":
+        x_local = x_local.to(torch.bfloat16)
     ids = torch.arange(n_local, device=dev)
     ids._spmi_identity = True
 
@@ -207,6 +230,23 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         if record:
             ev[0].record()
+        if kind == "evolve_bf16":
+            from spiral_amd.dtdg.types import Snapshot
+
+            g = G.SnapshotGraph(src, dst, n_total)
+            g.csr()
+            g.norm("in", 0)
+            g.norm("out", 0)
+            g.ndata["h"] = x_local
+            if record:
+                ev[1].record()
+                ev[2].record()
+            h, _ = model.encoder((Snapshot(g, t), ids))
+            if record:
+                ev[3].record()
+                ev[4].record()
+                stage_events.append(ev)
+            return h
         if world == 1:
             g = G.SnapshotGraph(src, dst, n_total)
             g.csr()
@@ -285,7 +325,8 @@ def main():
     _, _, nnz, n_rows, feat = launch_log[0]
     mean_nnz = sum(l[2] for l in launch_log) / len(launch_log)
     spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
-    alg_bytes = algorithmic_bytes(mean_nnz, n_rows, feat)
+    store_bytes = 2 if kind == "evolve_bf16" else 4
+    alg_bytes = algorithmic_bytes(mean_nnz, n_rows, feat, store_bytes)
     achieved = alg_bytes / (spmm_avg_ms * 1e-3) / 1e9
     stages = {}
     for i, name in enumerate(stage_names):
@@ -299,11 +340,15 @@ def main():
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16 storage, f32 accumulate" if kind == "evolve_bf16" else "f32",
+            "data": "synthetic",
             "config": {"workload": w["name"] + (f", x{world} row-partitioned" if world > 1 else ""),
                        "nodes": n_total, "edges_per_snapshot": e_total, "features": f,
                        "resident_snapshots": n_snap,
-                       "step": "COO->CSR+norm, 2x GraphConv(128->128, leaky_relu), 2-layer GRU(128) + MLP, "
+                       "step": ("COO->CSR+norm, weight GRU x2, 2x GraphConv (bf16 rows), "
+                                if kind == "evolve_bf16" else
+                                f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu), "
+                                f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
                        "parallelism": f"dst-row blocks x{world}" if world > 1 else "single GPU"},
             "aggregation_edges_per_s": mean_nnz * world / (spmm_avg_ms * 1e-3),
@@ -317,9 +362,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and kind == "gcn_gru":
             result["cpu_baseline"] = cpu_baseline(snapshots[0][0], snapshots[0][1], n_total, x_local, model)
-        elif world == 1:
+        else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
     if world > 1:

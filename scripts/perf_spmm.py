@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--thresh", type=int, default=G.HEAVY_THRESH)
     ap.add_argument("--chunk", type=int, default=G.HEAVY_CHUNK)
+    ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -53,13 +54,17 @@ def main():
     csr_t = G.build_csr(src, dst, a.n, a.n, a.thresh, a.chunk)
     print(f"n_heavy {csr.n_heavy} n_chunks {csr.n_chunks} max_deg {int(csr.degrees().max())}")
     x = torch.randn(a.n, a.f, device=dev)
+    sb = 4
+    if a.dtype == 'bf16':
+        x = x.to(torch.bfloat16)
+        sb = 2
     ss, ds = csr_t.norm(0), csr.norm(0)
     bias = torch.zeros(a.f, device=dev)
     ew = ss.index_select(0, csr.indices)
     med, best = timed(lambda: ss.index_select(0, csr.indices), 5)
     print(f'edge weight gather: {med:.3f} ms')
-    out = torch.empty(a.n, a.f, device=dev)
-    bytes_alg = a.e * (a.f * 4 + 4) + (a.n + 1) * 4 + 2 * a.n * 4 + a.n * a.f * 4 + a.f * 4
+    out = torch.empty(a.n, a.f, device=dev, dtype=x.dtype)
+    bytes_alg = a.e * (a.f * sb + 4) + (a.n + 1) * 4 + 2 * a.n * 4 + a.n * a.f * sb + a.f * 4
     for name, fn in (
         ("spmm plain", lambda: G.aggregate(csr, x, out=out)),
         ("spmm fused norm+bias+act", lambda: G.aggregate(csr, x, ss, None, ds, bias, "leaky_relu", 0.01, out=out)),

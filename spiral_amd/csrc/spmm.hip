@@ -44,17 +44,36 @@ struct VecOf<4> {
   using type = float __attribute__((ext_vector_type(4)));
 };
 
-// Feature rows are stored as float32 or bfloat16; sums are always float32.
+// Feature rows are stored as float32 or bfloat16; sums are always float32.  A gathered
+// row is kept as raw bits (Raw) until it is consumed: converting right at the load would
+// put a use inside the load's predicated region and make the compiler wait for every
+// load before issuing the next one, i.e. one row in flight instead of kUnroll.
 template <int VEC, typename T>
-__device__ __forceinline__ typename VecOf<VEC>::type load_row(const T* p) {
+struct RowOf {
+  using Raw = typename VecOf<VEC>::type;  // float32: the row itself
+};
+template <int VEC>
+struct RowOf<VEC, __bf16> {
+  using Raw = __bf16 __attribute__((ext_vector_type(VEC)));
+};
+template <>
+struct RowOf<1, __bf16> {
+  using Raw = __bf16;
+};
+
+template <int VEC, typename T>
+__device__ __forceinline__ typename RowOf<VEC, T>::Raw load_raw(const T* p) {
+  return *reinterpret_cast<const typename RowOf<VEC, T>::Raw*>(p);
+}
+template <int VEC, typename T>
+__device__ __forceinline__ typename VecOf<VEC>::type widen(typename RowOf<VEC, T>::Raw r) {
   using V = typename VecOf<VEC>::type;
   if constexpr (sizeof(T) == 4) {
-    return *reinterpret_cast<const V*>(p);
+    return r;
   } else if constexpr (VEC == 1) {
-    return static_cast<float>(*p);
+    return static_cast<float>(r);
   } else {
-    using B = __bf16 __attribute__((ext_vector_type(VEC)));
-    return __builtin_convertvector(*reinterpret_cast<const B*>(p), V);
+    return __builtin_convertvector(r, V);
   }
 }
 template <int VEC, typename T>
@@ -112,7 +131,7 @@ __device__ __forceinline__ typename VecOf<VEC>::type activate(typename VecOf<VEC
 // `flush(row, acc)` consumes a finished row; both are wave-uniform.
 template <int VEC, typename XT, typename RowEnd, typename Flush>
 __device__ __forceinline__ void stream_range(const SpmmParams& p, const XT* __restrict__ xcol,
-                                             bool fok, int lane, int s, int e, int row,
+                                             int lane, int s, int e, int row,
                                              int row_last, RowEnd row_end_of, Flush flush) {
   using V = typename VecOf<VEC>::type;
   V acc = V(0.0f);
@@ -128,15 +147,16 @@ __device__ __forceinline__ void stream_range(const SpmmParams& p, const XT* __re
       if (p.src_scale) w *= p.src_scale[my];
     }
     for (int k = 0; k < cnt; k += kUnroll) {
-      V v[kUnroll];
+      typename RowOf<VEC, XT>::Raw v[kUnroll];
       float wk[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int kk = min(k + u, cnt - 1);
         const int src = readlane_i(my, kk);
         wk[u] = weighted ? readlane_f(w, kk) : 1.0f;
-        v[u] = V(0.0f);
-        if (fok) v[u] = load_row<VEC, XT>(xcol + static_cast<int64_t>(src) * p.ldx);
+        // unconditional: lanes past the last feature column read column 0 instead (xcol is
+        // clamped by the caller), so no predicated region splits the batch of loads
+        v[u] = load_raw<VEC, XT>(xcol + static_cast<int64_t>(src) * p.ldx);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -148,7 +168,7 @@ __device__ __forceinline__ void stream_range(const SpmmParams& p, const XT* __re
             ++row;
             row_end = row_end_of(row);
           }
-          acc += wk[u] * v[u];
+          acc += wk[u] * widen<VEC, XT>(v[u]);
         }
       }
     }
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
   const bool heavy_lane = (lane < nr) && (ip_next - ip > p.heavy_thresh);
   const bool any_heavy = __ballot(heavy_lane) != 0ull;
 
-  const XT* xcol = static_cast<const XT*>(p.X) + f;
+  const XT* xcol = static_cast<const XT*>(p.X) + (fok ? f : 0);
   YT* ycol = static_cast<YT*>(p.Y) + f;
   auto row_end_of = [&](int row) { return readlane_i(ip, row + 1); };
   auto flush = [&](int row, V acc) {
@@ -194,13 +214,13 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
   };
 
   if (!any_heavy) {
-    stream_range<VEC, XT>(p, xcol, fok, lane, readlane_i(ip, 0), readlane_i(ip, nr), 0, nr - 1,
+    stream_range<VEC, XT>(p, xcol, lane, readlane_i(ip, 0), readlane_i(ip, nr), 0, nr - 1,
                           row_end_of, flush);
   } else {
     for (int row = 0; row < nr; ++row) {
       const int rs = readlane_i(ip, row), re = readlane_i(ip, row + 1);
       if (re - rs > p.heavy_thresh) continue;  // summed by the heavy-row kernels
-      stream_range<VEC, XT>(p, xcol, fok, lane, rs, re, row, row, row_end_of, flush);
+      stream_range<VEC, XT>(p, xcol, lane, rs, re, row, row, row_end_of, flush);
     }
   }
 }
@@ -237,7 +257,8 @@ __global__ __launch_bounds__(kThreads) void spmm_heavy_kernel(SpmmParams p,
   V total = V(0.0f);
   auto row_end_of = [&](int) { return INT_MAX; };
   auto flush = [&](int, V acc) { total = acc; };
-  stream_range<VEC, XT>(p, static_cast<const XT*>(p.X) + f, fok, lane, s, e, 0, 0, row_end_of, flush);
+  stream_range<VEC, XT>(p, static_cast<const XT*>(p.X) + (fok ? f : 0), lane, s, e, 0, 0, row_end_of,
+                        flush);
   s_part[wave][lane] = total;
   __syncthreads();
   if (wave == 0 && fok) {
