@@ -91,6 +91,25 @@ def gen_snapshot(n, e, t, k_dst, k_src, perm, dev):
     return src, dst
 
 
+def _stage_collectives_through_host():
+    """Rehearsal only: gloo moves host tensors, so wrap the collectives the path uses to copy
+    device tensors through the host.  Lets every rank of a rehearsal share one GPU."""
+    def staged(fn, out_pos):
+        def call(*args, **kw):
+            args = list(args)
+            dev_t = [a for a in args if isinstance(a, torch.Tensor)]
+            host = [a.cpu() if isinstance(a, torch.Tensor) else a for a in args]
+            r = fn(*host, **kw)
+            args[out_pos].copy_(host[out_pos])
+            return r
+        return call
+
+    dist.all_gather_into_tensor = staged(dist.all_gather_into_tensor, 0)
+    dist.reduce_scatter_tensor = staged(dist.reduce_scatter_tensor, 0)
+    dist.all_reduce = staged(dist.all_reduce, 0)
+    dist.broadcast = staged(dist.broadcast, 0)
+
+
 def algorithmic_bytes(e, n_rows, f, s=4):
     """Gather model of one fused aggregation launch; s = bytes per stored feature."""
     return e * (f * s + 4) + (n_rows + 1) * 4 + 2 * n_rows * 4 + n_rows * f * s + f * 4
@@ -181,10 +200,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SPMI_BENCH_REHEARSE=1: every rank on cuda:0 over gloo, to walk the multi-rank code path
+    # on a one-GPU box (not a measurement; RCCL needs one device per rank).
+    rehearse = os.environ.get("SPMI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+            _stage_collectives_through_host()
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     w = WORKLOADS[args.workload]
     n_total, e_total, f = w["n"] * world, w["e"] * world, w["f"]
@@ -195,9 +223,11 @@ def main():
     gen.manual_seed(99)
     perm = torch.randperm(n_total, generator=gen, device=dev)
     if world > 1:
+        dist.broadcast(perm, src=0)  # one permutation for all ranks, whatever their generators do
         src0, dst0 = gen_snapshot(n_total, e_total, 0, w["k_dst"], w["k_src"], perm, dev)
-        bounds = par.edge_balanced_bounds(G.degree(dst0, n_total), world)
-        part = par.RowPartition(n_total, bounds, rank, world)
+        bounds = [par.edge_balanced_bounds(G.degree(dst0, n_total), world)]
+        dist.broadcast_object_list(bounds, src=0)
+        part = par.RowPartition(n_total, bounds[0], rank, world)
         del src0, dst0
     else:
         part = par.RowPartition(n_total, [0, n_total], 0, 1)

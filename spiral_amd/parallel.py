@@ -139,6 +139,7 @@ class ShardedSnapshot(G.NormalisedAdjacency):
             else:
                 deg = kernels.degree(self.src_rows, self.part.n_gather)
                 if self.part.world > 1:
+                    deg = deg.to(torch.int32)  # degrees fit int32: half the bytes on the wire
                     dist.all_reduce(deg, group=self.group)
             d = deg.to(torch.float32).clamp_(min=1)
             self._norms[key] = d.sqrt_().reciprocal_() if mode == 0 else d.reciprocal_()
