@@ -19,7 +19,8 @@
  *     (spiro/dtdg/types.py:39); on-device CSR arrays are int32, which bounds
  *     one snapshot to N < 2^31 nodes and E < 2^31 edges (checked);
  *   - features are float32 like the reference's FEATURE_TYPE
- *     (spiro/dtdg/types.py:40), row-major with an explicit leading dimension.
+ *     (spiro/dtdg/types.py:40), row-major with an explicit leading dimension
+ *     (spmi_gcn_spmm_ex also accepts bfloat16 storage).
  */
 #ifndef SPMI_H
 #define SPMI_H
@@ -174,7 +175,7 @@ int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int
  *   saved         : nullable; when given, what the backward needs is stored
  *                   (GRU [M,5H]: r,z,n,hn,h_old ; LSTM [M,6H]: i,f,g,o,c_old,
  *                   tanh(c_new) ; RNN: nothing beyond h_out)
- * The *_prep entry points gather h_old rows into a dense [M,H] matrix for the
+ * spmi_gather_rows gathers h_old rows into a dense [M,H] matrix for the
  * caller's h W_hh^T GEMM when ids is not the identity.
  * ---------------------------------------------------------------------- */
 int spmi_gather_rows(const float* table, int64_t ld, const int64_t* ids, int64_t M, int64_t H,

@@ -1,5 +1,6 @@
+from .evolve import EvolveGCNO, WeightGRU
 from .graphconv import GraphConv
 from .sageconv import SAGEConv
 from .sgconv import SGConv
 
-__all__ = ["GraphConv", "SGConv", "SAGEConv"]
+__all__ = ["GraphConv", "SGConv", "SAGEConv", "EvolveGCNO", "WeightGRU"]
