@@ -87,6 +87,30 @@ int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*de
                     int32_t* status /*device [1]*/, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Cumulative snapshots.  Replaces the per-call rebuild of dgl.graph on the
+ * slice `edges[:anchor[t]]` in VEInvariantDTDG.dispatcher
+ * (spiro/dtdg/types.py:183-198) and the extra build of snapshot t-1 that
+ * CitationGraph.dispatcher makes only to read in-degrees (types.py:239-242).
+ * The time-sorted table is grouped once with spmi_coo_to_csr (with eid); as
+ * that grouping is stable, the edges [0, e_cut) of the table form a prefix of
+ * every row.  spmi_csr_prefix packs those row prefixes for the first n_rows
+ * rows: the result equals spmi_coo_to_csr run on the first e_cut edges with
+ * N = n_rows, bit for bit (indptr, indices and, when `eid` is given, eid).
+ * `status` is raised when an edge of the prefix touches a row >= n_rows or a
+ * column >= n_cols.  spmi_csr_prefix_degree returns only the prefix lengths
+ * (the degrees of that snapshot).
+ * ---------------------------------------------------------------------- */
+size_t spmi_csr_prefix_workspace_bytes(int64_t n_rows);
+int spmi_csr_prefix(const int32_t* indptr_all /*device [>= n_rows+1]*/,
+                    const int32_t* indices_all, const int32_t* eid_all /*device [E_all]*/,
+                    int64_t n_rows, int64_t n_cols, int64_t e_cut,
+                    int32_t* indptr /*device [n_rows+1]*/, int32_t* indices /*device [e_cut]*/,
+                    int32_t* eid /*nullable, device [e_cut]*/, void* ws, size_t ws_bytes,
+                    int32_t* status /*device [1]*/, void* stream);
+int spmi_csr_prefix_degree(const int32_t* indptr_all, const int32_t* eid_all, int64_t n_rows,
+                           int64_t e_cut, int64_t* deg /*device [n_rows]*/, void* stream);
+
+/* ------------------------------------------------------------------------
  * Degree -> normaliser.  Replaces `degs.float().clamp(min=1)` followed by
  * `torch.pow(degs, -0.5)` (norm='both') or `1.0/degs` (norm='right'/'left')
  * inside dgl GraphConv.forward (call sites staticGraphEncoder.py:113,116).

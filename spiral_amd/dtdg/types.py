@@ -18,7 +18,7 @@ from numpy import ndarray
 
 from spiral_amd.core.errors import DimensionError, ValueNotSortedError
 from spiral_amd.core.utils import get_anchor_position, is_sorted
-from spiral_amd.graph import SnapshotGraph, degree
+from spiral_amd.graph import EdgeTableIndex, SnapshotGraph, degree
 
 TIME_D = 0  # column of the time index in both tables
 SOURCE = 1
@@ -90,6 +90,8 @@ class VEInvariantDTDG(DiscreteGraph):
     timestamps: sorted array with one entry per observation.
     """
 
+    cumulative = True  # cut snapshot CSRs from one table-wide grouping instead of re-sorting
+
     def __init__(self, edges: ndarray, nodes: ndarray, timestamps: ndarray,
                  node_names: Optional[ndarray] = None, device=None):
         self.edge_dimension = 3
@@ -124,6 +126,13 @@ class VEInvariantDTDG(DiscreteGraph):
         if nodes.shape[1] > self.node_dimension:
             self._node_feat = torch.from_numpy(
                 nodes[:, self.node_dimension:].astype(np.float32)).to(self.device)
+        # Snapshots are prefixes of the table: group the table once (on first use) and cut
+        # every snapshot's CSR out of that grouping.  The row range covers every id of the
+        # table, so a snapshot whose edges run ahead of its nodes still fails on its own.
+        self._table: Optional[EdgeTableIndex] = None
+        if self.device.type == "cuda" and edges.shape[0] > 0:
+            top = int(max(edges[:, SOURCE].max(), edges[:, DESTINATION].max())) + 1
+            self._table = EdgeTableIndex(self._src, self._dst, max(top, nodes.shape[0], 1))
 
     @property
     def edge_id(self) -> Dict[str, int]:
@@ -142,7 +151,8 @@ class VEInvariantDTDG(DiscreteGraph):
     def dispatcher(self, t: int) -> Tuple[Snapshot, torch.Tensor]:
         """Snapshot of time index t (0-based) and the ids of its nodes."""
         n_edges, n_nodes = self._prefix(t)
-        observation = SnapshotGraph(self._src[:n_edges], self._dst[:n_edges], n_nodes)
+        table = self._table if (self.cumulative and n_nodes > 0) else None
+        observation = SnapshotGraph(self._src[:n_edges], self._dst[:n_edges], n_nodes, table=table)
         if self._edge_feat is not None:
             observation.edata[FEAT] = self._edge_feat[:n_edges]
         if self._node_feat is not None:
@@ -175,7 +185,10 @@ class CitationGraph(VEInvariantDTDG):
         hit = self._in_degree_cache.get(t)
         if hit is None:
             n_edges, n_nodes = self._prefix(t)
-            hit = degree(self._dst[:n_edges], n_nodes)
+            if self._table is not None and self.cumulative and n_nodes > 0:
+                hit = self._table.by_dst().prefix_degree(n_edges, n_nodes)
+            else:
+                hit = degree(self._dst[:n_edges], n_nodes)
             self._in_degree_cache[t] = hit
             while len(self._in_degree_cache) > self._DEGREE_CACHE:
                 self._in_degree_cache.popitem(last=False)

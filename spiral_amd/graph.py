@@ -82,6 +82,18 @@ class CSR:
         return out
 
 
+def _plan(indptr: torch.Tensor, n_rows: int, e: int, meta: torch.Tensor, heavy_thresh: int,
+          chunk: int):
+    """Queue the hub-row plan of the aggregation; meta[1:3] receives its two sizes."""
+    cap = e // heavy_thresh + 2
+    heavy_rows = torch.empty(cap, dtype=torch.int32, device=indptr.device)
+    heavy_ptr = torch.empty(cap, dtype=torch.int32, device=indptr.device)
+    nv.check(nv.lib().spmi_spmm_plan(nv.ptr(indptr), n_rows, heavy_thresh, chunk,
+                                     nv.ptr(heavy_rows), nv.ptr(heavy_ptr), cap, nv.ptr(meta[1:]),
+                                     nv.stream()), "spmi_spmm_plan")
+    return heavy_rows, heavy_ptr
+
+
 def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
               want_eid: bool = False) -> CSR:
@@ -103,17 +115,63 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
         nv.check(lib.spmi_coo_to_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
                                      nv.ptr(indices), nv.ptr(eid), nv.ptr(ws), ws_bytes,
                                      nv.ptr(meta), nv.stream()), "spmi_coo_to_csr")
-        cap = e // heavy_thresh + 2
-        heavy_rows = torch.empty(cap, dtype=torch.int32, device=dev)
-        heavy_ptr = torch.empty(cap, dtype=torch.int32, device=dev)
-        nv.check(lib.spmi_spmm_plan(nv.ptr(indptr), n_key, heavy_thresh, chunk, nv.ptr(heavy_rows),
-                                    nv.ptr(heavy_ptr), cap, nv.ptr(meta[1:]), nv.stream()),
-                 "spmi_spmm_plan")
+        heavy_rows, heavy_ptr = _plan(indptr, n_key, e, meta, heavy_thresh, chunk)
         status, n_heavy, n_chunks = meta.tolist()
     if status != 0:
         raise nv.SpmiError(f"edge list holds a node id outside [0, {n_key}) / [0, {n_other})")
     return CSR(indptr, indices, eid, n_key, n_other, e, heavy_rows, heavy_ptr, n_heavy, n_chunks,
                heavy_thresh, chunk)
+
+
+class CumulativeCSR:
+    """One grouping of a whole time-sorted edge table, from which the CSR of any time
+    prefix `edges[:e_cut]` is cut without sorting again (the reference rebuilds the graph
+    of every prefix from scratch, spiro/dtdg/types.py:183-198).  The grouping is stable, so
+    the edges of a prefix are a prefix of every row."""
+
+    def __init__(self, key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int):
+        self.full = build_csr(key, other, n_key, n_other, want_eid=True)
+
+    def _check(self, e_cut: int, n_rows: int) -> None:
+        if not (0 <= e_cut <= self.full.nnz and 1 <= n_rows <= self.full.n_rows):
+            raise nv.SpmiError(f"prefix (e_cut={e_cut}, n_rows={n_rows}) outside the table "
+                               f"({self.full.nnz} edges, {self.full.n_rows} rows)")
+
+    def prefix(self, e_cut: int, n_rows: int, n_cols: int, want_eid: bool = False,
+               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK) -> CSR:
+        """CSR of the first `e_cut` edges over rows [0, n_rows): bit-identical to
+        `build_csr(key[:e_cut], other[:e_cut], n_rows, n_cols)`."""
+        self._check(e_cut, n_rows)
+        full, lib = self.full, nv.lib()
+        dev = full.indptr.device
+        with torch.cuda.device(dev):
+            indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+            indices = torch.empty(e_cut, dtype=torch.int32, device=dev)
+            eid = torch.empty(e_cut, dtype=torch.int32, device=dev) if want_eid else None
+            meta = torch.zeros(3, dtype=torch.int32, device=dev)
+            ws_bytes = lib.spmi_csr_prefix_workspace_bytes(n_rows)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            nv.check(lib.spmi_csr_prefix(nv.ptr(full.indptr), nv.ptr(full.indices), nv.ptr(full.eid),
+                                         n_rows, n_cols, e_cut, nv.ptr(indptr), nv.ptr(indices),
+                                         nv.ptr(eid), nv.ptr(ws), ws_bytes, nv.ptr(meta),
+                                         nv.stream()), "spmi_csr_prefix")
+            heavy_rows, heavy_ptr = _plan(indptr, n_rows, e_cut, meta, heavy_thresh, chunk)
+            status, n_heavy, n_chunks = meta.tolist()
+        if status != 0:
+            raise nv.SpmiError(f"edge list holds a node id outside [0, {n_rows}) / [0, {n_cols})")
+        return CSR(indptr, indices, eid, n_rows, n_cols, e_cut, heavy_rows, heavy_ptr, n_heavy,
+                   n_chunks, heavy_thresh, chunk)
+
+    def prefix_degree(self, e_cut: int, n_rows: int) -> torch.Tensor:
+        """int64 degrees of rows [0, n_rows) in the first `e_cut` edges."""
+        self._check(e_cut, n_rows)
+        full = self.full
+        with torch.cuda.device(full.indptr.device):
+            out = torch.empty(n_rows, dtype=torch.int64, device=full.indptr.device)
+            nv.check(nv.lib().spmi_csr_prefix_degree(nv.ptr(full.indptr), nv.ptr(full.eid), n_rows,
+                                                     e_cut, nv.ptr(out), nv.stream()),
+                     "spmi_csr_prefix_degree")
+        return out
 
 
 def degree(ids: torch.Tensor, n: int) -> torch.Tensor:
@@ -217,6 +275,26 @@ class NormalisedAdjacency:
         return w
 
 
+class EdgeTableIndex:
+    """Table-wide groupings (by destination and by source) of a time-sorted edge table,
+    built on first use and shared by every prefix snapshot of the table."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_nodes: int):
+        self._src, self._dst, self._n = src, dst, int(n_nodes)
+        self._by_dst: Optional[CumulativeCSR] = None
+        self._by_src: Optional[CumulativeCSR] = None
+
+    def by_dst(self) -> CumulativeCSR:
+        if self._by_dst is None:
+            self._by_dst = CumulativeCSR(self._dst, self._src, self._n, self._n)
+        return self._by_dst
+
+    def by_src(self) -> CumulativeCSR:
+        if self._by_src is None:
+            self._by_src = CumulativeCSR(self._src, self._dst, self._n, self._n)
+        return self._by_src
+
+
 class _FrameDict(dict):
     """ndata / edata: feature name -> tensor, checked against the number of rows."""
 
@@ -235,7 +313,10 @@ class SnapshotGraph(NormalisedAdjacency):
     """Stand-in for the `dgl.DGLGraph` of one snapshot (homogeneous, directed, multi-edges
     and self-loops kept, edge ids = positions in the COO list)."""
 
-    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: Optional[int] = None):
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: Optional[int] = None,
+                 table: Optional["EdgeTableIndex"] = None):
+        """`table`: set when (src, dst) are the first len(src) rows of a time-sorted edge
+        table that keeps table-wide groupings; the CSRs are then cut from those."""
         src, dst = torch.as_tensor(src), torch.as_tensor(dst)
         if src.shape != dst.shape or src.dim() != 1:
             raise ValueError("src and dst must be 1-D tensors of equal length")
@@ -251,6 +332,7 @@ class SnapshotGraph(NormalisedAdjacency):
         self._csr_t: Optional[CSR] = None    # grouped by source
         self._out_deg: Optional[torch.Tensor] = None
         self._norms: Dict[Tuple[str, int], torch.Tensor] = {}
+        self._table = table
 
     # ---- DGLGraph surface used by the reference -----------------------------------
     @property
@@ -290,7 +372,10 @@ class SnapshotGraph(NormalisedAdjacency):
         if self._csr_t is not None:
             return self._csr_t.degrees()
         if self._out_deg is None:
-            self._out_deg = degree(self._src, self._n)
+            if self._table is not None:
+                self._out_deg = self._table.by_src().prefix_degree(self._src.numel(), self._n)
+            else:
+                self._out_deg = degree(self._src, self._n)
         return self._out_deg
 
     def add_self_loop(self) -> "SnapshotGraph":
@@ -313,6 +398,7 @@ class SnapshotGraph(NormalisedAdjacency):
         keep = torch.ones(self._src.numel(), dtype=torch.bool, device=self.device)
         keep[eids] = False
         self._src, self._dst = self._src[keep], self._dst[keep]
+        self._table = None  # no longer a prefix of the table
         edata = _FrameDict(self._src.numel(), "edges")
         for k, v in self.edata.items():
             edata[k] = v[keep]
@@ -335,12 +421,19 @@ class SnapshotGraph(NormalisedAdjacency):
     # ---- device structures ------------------------------------------------------------
     def csr(self, want_eid: bool = False) -> CSR:
         if self._csr is None or (want_eid and self._csr.eid is None):
-            self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid)
+            if self._table is not None and self._src.numel() > 0:
+                self._csr = self._table.by_dst().prefix(self._src.numel(), self._n, self._n, want_eid)
+            else:
+                self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid)
         return self._csr
 
     def csr_t(self, want_eid: bool = False) -> CSR:
         if self._csr_t is None or (want_eid and self._csr_t.eid is None):
-            self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid)
+            if self._table is not None and self._src.numel() > 0:
+                self._csr_t = self._table.by_src().prefix(self._src.numel(), self._n, self._n,
+                                                          want_eid)
+            else:
+                self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid)
         return self._csr_t
 
     def norm(self, side: str, mode: int) -> torch.Tensor:
