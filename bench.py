@@ -94,14 +94,20 @@ def gen_snapshot(n, e, t, k_dst, k_src, perm, dev):
 def _stage_collectives_through_host():
     """Rehearsal only: gloo moves host tensors, so wrap the collectives the path uses to copy
     device tensors through the host.  Lets every rank of a rehearsal share one GPU."""
+    class Done:
+        def wait(self):
+            return True
+
     def staged(fn, out_pos):
         def call(*args, **kw):
             args = list(args)
-            dev_t = [a for a in args if isinstance(a, torch.Tensor)]
             host = [a.cpu() if isinstance(a, torch.Tensor) else a for a in args]
+            was_async = kw.pop("async_op", False)
+            if host[out_pos].dtype == torch.bfloat16:  # gloo moves bytes
+                host = [a.view(torch.uint8) if isinstance(a, torch.Tensor) else a for a in host]
             r = fn(*host, **kw)
-            args[out_pos].copy_(host[out_pos])
-            return r
+            args[out_pos].copy_(host[out_pos].view(args[out_pos].dtype))
+            return Done() if was_async else r
         return call
 
     dist.all_gather_into_tensor = staged(dist.all_gather_into_tensor, 0)
@@ -190,6 +196,12 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--snapshots", type=int, default=0, help="distinct resident snapshots (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="pipelined", choices=["pipelined", "plain"],
+                    help="N>1, forward: 'pipelined' projects the replicated input of layer 1 on every "
+                         "rank (no exchange) and overlaps the layer-2 all-gather of snapshot t with the "
+                         "recurrent update of snapshot t-1; 'plain' gathers in front of both layers")
+    ap.add_argument("--gather-dtype", default="f32", choices=["f32", "bf16"],
+                    help="N>1: payload of the all-gather (bf16 halves the bytes; sums stay f32)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: forward + MSE loss + backward + Adam step per snapshot "
                          "(the loop of examples/torch/citation_prediction.py:90-101)")
@@ -240,7 +252,7 @@ def main():
             keep = (dst >= lo) & (dst < hi)
             src, dst = src[keep].contiguous(), dst[keep].contiguous()
         snapshots.append((src, dst))
-    gen.manual_seed(7)
+    gen.manual_seed(7 + 1000 * rank)
     x_local = torch.randn(n_local, f, generator=gen, device=dev)
     torch.manual_seed(11)
     kind = w.get("model", "gcn_gru")
@@ -251,6 +263,19 @@ def main():
         x_local = x_local.to(torch.bfloat16)
     ids = torch.arange(n_local, device=dev)
     ids._spmi_identity = True
+    pipelined = world > 1 and args.mode == "forward" and args.exchange == "pipelined"
+    payload = torch.bfloat16 if args.gather_dtype == "bf16" else None
+    if pipelined:
+        # the node features never change: every rank holds the whole matrix, in the row
+        # layout the gathered matrices use (own block = the x_local generated above)
+        xs = []
+        for q in range(world):
+            qlo, qhi = part.block(q)
+            gen.manual_seed(7 + 1000 * q)
+            xs.append(torch.randn(qhi - qlo, f, generator=gen, device=dev))
+        x_local = xs[rank]
+        x_repl = par.replicate_rows(torch.cat(xs), part)
+        del xs
 
     stage_names = ("csr_build", "conv1", "conv2", "recurrent")
     stage_events = []
@@ -307,6 +332,53 @@ def main():
             stage_events.append(ev)
         return out
 
+    # ---- N>1 forward: one snapshot in two halves, the exchange in between ----------------
+    # front(t): CSR + norms, layer 1 on the replicated input (no exchange), projection of
+    # layer 2, start of its all-gather.  back(t): layer-2 aggregation, recurrent update,
+    # MLP.  step t runs front(t) and then back(t-1): the rows of snapshot t travel while
+    # snapshot t-1 is finished and snapshot t+1 is started.  Outputs equal the plain order
+    # (encoders of different snapshots are independent, the recurrent order is kept).
+    in_flight = []
+    # The small out-degree all-reduce of snapshot t+1 must not queue behind the gather of
+    # snapshot t on the communicator's stream: it gets a communicator of its own.
+    deg_group = dist.new_group() if pipelined else None
+
+    def front(t, ev):
+        src, dst = snapshots[t % n_snap]
+        shard = par.ShardedSnapshot(src, dst, part, group=deg_group)
+        shard.csr()
+        shard.norm("in", 0)
+        shard.norm("out", 0)
+        if ev:
+            ev[1].record()
+        h = par.graphconv_aggregate(model.conv1, shard, par.graphconv_project(model.conv1, x_repl))
+        if ev:
+            ev[2].record()
+        pending = par.gather_rows_async(par.graphconv_project(model.conv2, h), part, None, payload)
+        in_flight.append((shard, pending))
+
+    def back(ev):
+        shard, pending = in_flight.pop(0)
+        if ev:
+            ev[3].record()
+        h = par.graphconv_aggregate(model.conv2, shard, pending.wait())
+        if ev:
+            ev[4].record()
+        out = model.rnn((h, ids))
+        if ev:
+            ev[5].record()
+        return out
+
+    def pipelined_step(t, record):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if record else None
+        if ev:
+            ev[0].record()
+        front(t, ev)
+        out = back(ev) if len(in_flight) > 1 else None
+        if ev and out is not None:
+            stage_events.append(ev)
+        return out
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -322,6 +394,9 @@ def main():
         label = torch.randn(n_local, device=dev)
 
     def run(i, record):
+        if pipelined:
+            with torch.no_grad():
+                return pipelined_step(i, record)
         if not train:
             with torch.no_grad():
                 return step(i, record)
@@ -333,14 +408,21 @@ def main():
         opt.step()
         return loss
 
+    def drain():
+        with torch.no_grad():
+            while in_flight:
+                back(None)
+
     for i in range(args.warmup):
         run(i, False)
+    drain()  # the timed region starts with an empty pipeline ...
     launch_log = []
     G.set_launch_log(launch_log)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(args.warmup + i, True)
+    drain()  # ... and ends with it empty: exactly `steps` whole snapshots inside
     barrier()
     elapsed = time.perf_counter() - t0
     G.set_launch_log(None)
@@ -359,8 +441,13 @@ def main():
     alg_bytes = algorithmic_bytes(mean_nnz, n_rows, feat, store_bytes)
     achieved = alg_bytes / (spmm_avg_ms * 1e-3) / 1e9
     stages = {}
+    if pipelined:
+        # front(t): [0,1) CSR, [1,2) layer 1, [2,3) projection + gather start;
+        # back(t-1): [3,4) wait + layer-2 aggregation, [4,5) recurrent
+        stage_names = ("csr_build", "conv1_replicated_input", "conv2_project", "conv2_wait_aggregate",
+                       "recurrent")
     for i, name in enumerate(stage_names):
-        stages[name + "_ms"] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_events) / len(stage_events)
+        stages[name + "_ms"] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_events) / max(len(stage_events), 1)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -380,7 +467,11 @@ def main():
                                 f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu), "
                                 f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
-                       "parallelism": f"dst-row blocks x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"dst-row blocks x{world}, all-gather per layer" +
+                                       (", layer-1 input replicated, layer-2 gather overlapped with the "
+                                        "previous snapshot's recurrent update" if pipelined else "") +
+                                       (", bf16 gather payload" if payload is not None else ""))
+                       if world > 1 else "single GPU"},
             "aggregation_edges_per_s": mean_nnz * world / (spmm_avg_ms * 1e-3),
             "stages": stages,
             "roofline": {

@@ -16,6 +16,14 @@ Weight and bias gradients are summed with one all-reduce after the backward
 Blocks are padded to the largest block so that one `all_gather_into_tensor` /
 `reduce_scatter_tensor` moves everything; source ids are remapped once per snapshot to
 rows of the padded gathered matrix, so no compaction pass runs after the collective.
+
+At 8 GPUs the gather, not the kernels, bounds a layer (every rank ingests 7/8 of the
+projected matrix).  Two ways around it are provided for inference loops: a layer whose
+input never changes and is held by every rank (`replicate_rows`) is projected redundantly
+and needs no exchange at all, and the layer is available in two halves
+(`graphconv_project` -> `gather_rows_async` ... `PendingGather.wait` ->
+`graphconv_aggregate`) so that independent work, e.g. the recurrent update of the previous
+snapshot, runs while the rows travel.
 """
 from __future__ import annotations
 
@@ -183,34 +191,117 @@ def sharded_aggregate(shard: ShardedSnapshot, x_local: torch.Tensor, norm: str =
     return _ShardedAggregate.apply(x_local, bias, shard, norm, act, slope)
 
 
+def _split_activation(conv):
+    from .nn.graphconv import _classify_activation
+
+    return _classify_activation(conv._activation)
+
+
+def _finish(conv, rst: torch.Tensor, code, slope, unfused) -> torch.Tensor:
+    """What follows the aggregation when the layer aggregates first (in_feats < out_feats)."""
+    import torch.nn.functional as F
+
+    weight = conv.weight
+    if weight is not None:
+        rst = torch.addmm(conv.bias, rst, weight) if conv.bias is not None else rst @ weight
+    elif conv.bias is not None:
+        rst = rst + conv.bias
+    if code == "relu":
+        rst = F.relu(rst)
+    elif code == "leaky_relu":
+        rst = F.leaky_relu(rst, slope)
+    return rst if unfused is None else unfused(rst)
+
+
 def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) -> torch.Tensor:
     """A spiral_amd GraphConv layer applied to this rank's rows of a sharded snapshot:
     same parameters and order of operations as GraphConv.forward, with the all-gather in
-    front of the aggregation (after X W when in_feats > out_feats, so the smaller matrix
+    front of the aggregation (after X W when in_feats >= out_feats, so the smaller matrix
     travels)."""
-    from .nn.graphconv import _classify_activation
-    import torch.nn.functional as F
-
     norm = conv._norm
-    code, slope, unfused = _classify_activation(conv._activation)
-    weight = conv.weight
+    code, slope, unfused = _split_activation(conv)
     if conv._in_feats >= conv._out_feats:
-        if weight is not None:
-            feat_local = feat_local @ weight
+        if conv.weight is not None:
+            feat_local = feat_local @ conv.weight
         rst = sharded_aggregate(shard, feat_local, norm, conv.bias, code, slope)
+        return rst if unfused is None else unfused(rst)
+    return _finish(conv, sharded_aggregate(shard, feat_local, norm), code, slope, unfused)
+
+
+# ---- the same layer in two halves, for callers that overlap the exchange -----------------
+def replicate_rows(x_global: torch.Tensor, part: RowPartition) -> torch.Tensor:
+    """Padded-gather layout [world * max_block, F] of a matrix every rank holds in full
+    (input features that never change, e.g. the node table of a VEInvariantDTDG)."""
+    out = x_global.new_zeros(part.n_gather, x_global.shape[1])
+    rows = part.padded_rows(torch.arange(part.n, dtype=torch.int64, device=x_global.device))
+    out[rows] = x_global
+    return out
+
+
+class PendingGather:
+    """An all-gather of source rows in flight (or finished).  `wait()` returns the gathered
+    padded matrix; the exchange runs on the communicator's own stream, so whatever the
+    caller launches between `gather_rows_async` and `wait` overlaps it."""
+
+    def __init__(self, out: torch.Tensor, send: torch.Tensor, work):
+        self._out, self._send, self._work = out, send, work
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._send = None
+        return self._out
+
+
+def gather_rows_async(x_local: torch.Tensor, part: RowPartition, group=None,
+                      payload_dtype: Optional[torch.dtype] = None) -> PendingGather:
+    """Start the all-gather of this rank's (projected) rows.  payload_dtype=torch.bfloat16
+    halves the bytes on the wire; the aggregation then reads bfloat16 rows and still sums in
+    float32 (a documented precision trade, off by default)."""
+    send = x_local.detach()
+    if payload_dtype is not None and send.dtype != payload_dtype:
+        send = send.to(payload_dtype)
+    if send.shape[0] != part.max_block or not send.is_contiguous():
+        padded = send.new_zeros(part.max_block, send.shape[1])
+        padded[: send.shape[0]] = send
+        send = padded
+    out = send.new_empty(part.n_gather, send.shape[1])
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
+    return PendingGather(out, send, work)
+
+
+def graphconv_project(conv, feat: torch.Tensor) -> torch.Tensor:
+    """First half of a layer: the rows that have to reach every rank (X W when the layer
+    multiplies first, X itself otherwise).  Row-local, so it applies to a rank's own rows
+    or to a replicated matrix alike."""
+    if conv._in_feats >= conv._out_feats and conv.weight is not None:
+        return feat @ conv.weight
+    return feat
+
+
+def graphconv_aggregate(conv, shard: ShardedSnapshot, z_full: torch.Tensor) -> torch.Tensor:
+    """Second half: aggregation of the gathered (or replicated) projected rows into this
+    rank's destination block, then bias/activation (and W when the layer aggregates
+    first).  Differentiable with respect to `z_full` and the layer parameters; the gradient
+    of `z_full` is this rank's partial sum over its own edges."""
+    norm = conv._norm
+    code, slope, unfused = _split_activation(conv)
+    first = conv._in_feats >= conv._out_feats
+    if z_full.dtype != torch.float32:
+        # reduced-precision payload (inference only): float32 sums and a float32 result
+        mode = 0 if norm == "both" else 1
+        dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
+        bias = conv.bias.detach() if (first and conv.bias is not None) else None
+        rst = kernels.aggregate(shard.csr(), z_full.detach(), None, shard.edge_scale("fwd", norm),
+                                dst_scale, bias, code if first else None, slope,
+                                out_dtype=torch.float32)
     else:
-        rst = sharded_aggregate(shard, feat_local, norm)
-        if weight is not None:
-            rst = torch.addmm(conv.bias, rst, weight) if conv.bias is not None else rst @ weight
-        elif conv.bias is not None:
-            rst = rst + conv.bias
-        if code == "relu":
-            rst = F.relu(rst)
-        elif code == "leaky_relu":
-            rst = F.leaky_relu(rst, slope)
-    if unfused is not None:
-        rst = unfused(rst)
-    return rst
+        rst = ops.gcn_aggregate(shard, z_full, norm, conv.bias if first else None, None,
+                                code if first else None, slope)
+    if first:
+        return rst if unfused is None else unfused(rst)
+    return _finish(conv, rst, code, slope, unfused)
 
 
 def allreduce_gradients(module: torch.nn.Module, group=None) -> None:

@@ -15,13 +15,20 @@ pytestmark = pytest.mark.gpu
 
 
 def _stage_through_host():
+    class Done:
+        def wait(self):
+            return True
+
     def staged(fn):
         def call(*args, **kw):
             args = list(args)
             host = [a.cpu() if isinstance(a, torch.Tensor) else a for a in args]
+            was_async = kw.pop("async_op", False)
+            if host[0].dtype == torch.bfloat16:  # gloo moves bytes
+                host = [a.view(torch.uint8) if isinstance(a, torch.Tensor) else a for a in host]
             r = fn(*host, **kw)
-            args[0].copy_(host[0])
-            return r
+            args[0].copy_(host[0].view(args[0].dtype))
+            return Done() if was_async else r
         return call
 
     for name in ("all_gather_into_tensor", "reduce_scatter_tensor", "all_reduce"):
@@ -51,6 +58,19 @@ def _layer(fi, fo, w, b, dev):
     return conv
 
 
+def _two_layers(fi, dev):
+    import torch.nn.functional as F
+    from spiral_amd.core.types import GraphConv
+
+    torch.manual_seed(5)
+    conv1 = GraphConv(fi, 64, activation=F.leaky_relu, allow_zero_in_degree=True).to(dev)
+    conv2 = GraphConv(64, 96, activation=F.relu, allow_zero_in_degree=True).to(dev)  # aggregates first
+    with torch.no_grad():
+        conv1.bias.normal_()
+        conv2.bias.normal_()
+    return conv1, conv2
+
+
 def _worker(rank, world, port, results):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,8 +91,44 @@ def _worker(rank, world, port, results):
         y = par.sharded_graphconv(conv, shard, xl)
         (y ** 2).sum().backward()
         par.allreduce_gradients(conv)
-        results[rank] = dict(bounds=bounds, y=y.detach().cpu().numpy(), gx=xl.grad.cpu().numpy(),
-                             gw=conv.weight.grad.cpu().numpy(), gb=conv.bias.grad.cpu().numpy())
+        out = dict(bounds=bounds, y=y.detach().cpu().numpy(), gx=xl.grad.cpu().numpy(),
+                   gw=conv.weight.grad.cpu().numpy(), gb=conv.bias.grad.cpu().numpy())
+
+        # the layer in two halves: replicated input (no exchange) for layer 1, the gather of
+        # layer 2 in flight while the next snapshot's front half runs
+        from oracle import oracle as orc
+
+        conv1, conv2 = _two_layers(x.shape[1], dev)
+        x_repl = par.replicate_rows(torch.from_numpy(x).to(dev), part)
+        deg_group = dist.new_group()
+        in_flight, h2, h2_bf16 = [], [], []
+        with torch.no_grad():
+            for t in range(3):
+                s_np, d_np = orc.powerlaw_snapshot(n, 30_000, t=t, k_dst=4.0)
+                sh = par.ShardedSnapshot.from_global(torch.from_numpy(s_np).to(dev),
+                                                     torch.from_numpy(d_np).to(dev), part, deg_group)
+                h1 = par.graphconv_aggregate(conv1, sh, par.graphconv_project(conv1, x_repl))
+                z2 = par.graphconv_project(conv2, h1)
+                in_flight.append((sh, par.gather_rows_async(z2, part),
+                                  par.gather_rows_async(z2, part, None, torch.bfloat16)))
+                if len(in_flight) > 1:
+                    sh0, p32, p16 = in_flight.pop(0)
+                    h2.append(par.graphconv_aggregate(conv2, sh0, p32.wait()).cpu().numpy())
+                    h2_bf16.append(par.graphconv_aggregate(conv2, sh0, p16.wait()).cpu().numpy())
+            while in_flight:
+                sh0, p32, p16 = in_flight.pop(0)
+                h2.append(par.graphconv_aggregate(conv2, sh0, p32.wait()).cpu().numpy())
+                h2_bf16.append(par.graphconv_aggregate(conv2, sh0, p16.wait()).cpu().numpy())
+        out.update(h2=h2, h2_bf16=h2_bf16)
+
+        # gradients through the replicated-input layer: every rank's partial, summed
+        conv1.zero_grad()
+        y1 = par.graphconv_aggregate(conv1, shard, par.graphconv_project(conv1, x_repl))
+        (y1 ** 2).sum().backward()
+        par.allreduce_gradients(conv1)
+        out.update(y1=y1.detach().cpu().numpy(), gw1=conv1.weight.grad.cpu().numpy(),
+                   gb1=conv1.bias.grad.cpu().numpy())
+        results[rank] = out
     finally:
         dist.destroy_process_group()
 
@@ -106,3 +162,28 @@ def test_two_ranks_on_one_gpu_equal_single_gpu(dev):
         assert rel(results[r]["gx"], xg.grad[lo:hi]) < 1e-5
         assert rel(results[r]["gw"], conv.weight.grad) < 1e-5
         assert rel(results[r]["gb"], conv.bias.grad) < 1e-5
+
+
+    # two-half layers, exchange in flight across snapshots: same numbers as the plain order
+    from oracle import oracle as orc
+
+    conv1, conv2 = _two_layers(x.shape[1], dev)
+    xt = torch.from_numpy(x).to(dev)
+    for t in range(3):
+        s_np, d_np = orc.powerlaw_snapshot(n, 30_000, t=t, k_dst=4.0)
+        gt = SnapshotGraph(torch.from_numpy(s_np).to(dev), torch.from_numpy(d_np).to(dev), n)
+        with torch.no_grad():
+            want = conv2(gt, conv1(gt, xt))
+        for r in range(world):
+            lo, hi = bounds[r], bounds[r + 1]
+            assert rel(results[r]["h2"][t], want[lo:hi]) < 1e-5
+            # bfloat16 payload: inputs rounded once (2^-9 relative), float32 sums
+            assert rel(results[r]["h2_bf16"][t], want[lo:hi]) < 1e-2
+    conv1.zero_grad()
+    y1 = conv1(g, xt)
+    (y1 ** 2).sum().backward()
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        assert rel(results[r]["y1"], y1[lo:hi]) < 1e-5
+        assert rel(results[r]["gw1"], conv1.weight.grad) < 1e-5
+        assert rel(results[r]["gb1"], conv1.bias.grad) < 1e-5

@@ -135,3 +135,38 @@ def test_bounds_and_padded_layout():
     assert part.padded_rows(ids).tolist() == [0, 2, 7, 13]
     one = par.edge_balanced_bounds(deg, 1)
     assert one == [0, 10]
+
+
+def _gather_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, f = 11, 3
+        part = par.RowPartition(n, [0, 4, 11], rank, world)
+        x = torch.arange(n * f, dtype=torch.float32).reshape(n, f)
+        lo, hi = part.block()
+        pending = par.gather_rows_async(x[lo:hi] * 2.0, part)
+        repl = par.replicate_rows(x, part)  # independent work while the rows travel
+        results[rank] = dict(gathered=pending.wait().numpy(), repl=repl.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_gather_and_replicated_layout_agree():
+    """The gathered matrix of per-rank blocks and the replicated layout of the same global
+    matrix address rows identically (RowPartition.padded_rows); padding rows are zero."""
+    world = 2
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_gather_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+        results = dict(results)
+    n, f = 11, 3
+    x = np.arange(n * f, dtype=np.float32).reshape(n, f)
+    part = par.RowPartition(n, [0, 4, 11], 0, world)
+    rows = part.padded_rows(torch.arange(n)).numpy()
+    for r in range(world):
+        assert results[r]["gathered"].shape == (part.n_gather, f)
+        np.testing.assert_array_equal(results[r]["gathered"][rows], 2.0 * x)
+        np.testing.assert_array_equal(results[r]["repl"][rows], x)
+        pad = np.setdiff1d(np.arange(part.n_gather), rows)
+        assert not results[r]["repl"][pad].any() and not results[r]["gathered"][pad].any()
