@@ -245,6 +245,45 @@ int spmi_cell_fused_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
                         float* c_out, int mem_write, float* saved, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Attention encoder.  Replace what dgl GATConv.forward runs on the graph
+ * (reference call sites: GAT in staticGraphEncoder.py:170,174,190):
+ * apply_edges(u_add_v('el','er')), LeakyReLU(negative_slope), edge_softmax
+ * over the incoming edges of every destination, and their gradients.  The
+ * weighted sum update_all(u_mul_e('ft','a'), sum) is spmi_gcn_spmm with
+ * edge_w = one head of `attn`, one launch per head on the column slice of
+ * that head.
+ *   per-edge arrays are head-major [H, E] in the order of the CSR given;
+ *   el [n_src, H], er [n_rows, H]: attention logits of sources / destinations;
+ *   raw (nullable): el[src]+er[dst] before LeakyReLU, kept for the backward;
+ *   heavy_rows / n_heavy / heavy_thresh: the hub-row list of spmi_spmm_plan
+ *   (rows above the threshold are reduced by a whole workgroup).
+ * Rows without entries are left untouched by the softmax and get zero from
+ * the backward and from spmi_segment_sum.
+ * ---------------------------------------------------------------------- */
+int spmi_gat_edge_softmax(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t E,
+                          const float* el, const float* er, int32_t H, float slope,
+                          float* attn /*[H,E]*/, float* raw /*nullable [H,E]*/,
+                          const int32_t* heavy_rows, int32_t n_heavy, int32_t heavy_thresh,
+                          void* stream);
+/* d_raw = attn * (d_attn - sum_row(attn * d_attn)) * LeakyReLU'(raw); d_er = row sums of d_raw */
+int spmi_gat_edge_softmax_bwd(const int32_t* indptr, int64_t n_rows, int64_t E, const float* attn,
+                              const float* raw, const float* d_attn, int32_t H, float slope,
+                              float* d_raw /*[H,E]*/, float* d_er /*[n_rows,H]*/,
+                              const int32_t* heavy_rows, int32_t n_heavy, int32_t heavy_thresh,
+                              void* stream);
+/* out[r,h] = sum of vals[h, j] over the entries j of row r (d_el on the by-source CSR) */
+int spmi_segment_sum(const int32_t* indptr, int64_t n_rows, int64_t E, const float* vals /*[H,E]*/,
+                     int32_t H, float* out /*[n_rows,H]*/, const int32_t* heavy_rows,
+                     int32_t n_heavy, int32_t heavy_thresh, void* stream);
+/* out[h,j] = <A[row(j), h*D:(h+1)*D], B[indices[j], h*D:(h+1)*D]>: gradient of the
+ * attention weights, A = d(output) rows of destinations, B = projected source rows.
+ * D must be a power of two below 64 or a multiple of 64, H*D <= 512. */
+int spmi_sddmm_dot_supported(int32_t H, int32_t D);
+int spmi_sddmm_dot(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t E,
+                   const float* A, int64_t lda, const float* B, int64_t ldb, int32_t H, int32_t D,
+                   float* out /*[H,E]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

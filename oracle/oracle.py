@@ -277,6 +277,41 @@ def sageconv_gcn_torch(src, dst, n, x, weight, bias, act=None, slope=0.01):
     return rst
 
 
+def gatconv_torch(src, dst, n, x, fc_weight, attn_l, attn_r, bias, heads, negative_slope=0.2,
+                  act=None, slope=0.01, res_weight=None, residual=False):
+    """DGL 0.8 GATConv.forward in differentiable torch index ops (GATConv is the layer the
+    reference's GAT encoder stacks, staticGraphEncoder.py:170,174): ft = fc(x) viewed
+    [N,H,D]; el/er = (ft * attn).sum(-1); e = LeakyReLU(el[src] + er[dst]); a = softmax of e
+    over the incoming edges of each destination; out = sum a * ft[src] (+ residual) + bias,
+    activation.  Returns (out [N,H,D], a [E,H,1] in edge order)."""
+    import torch
+
+    src_t = torch.as_tensor(np.asarray(src), dtype=torch.long)
+    dst_t = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+    d = fc_weight.shape[0] // heads
+    ft = (x @ fc_weight.t()).view(-1, heads, d)
+    el = (ft * attn_l).sum(-1)
+    er = (ft * attn_r).sum(-1)
+    e = torch.nn.functional.leaky_relu(el[src_t] + er[dst_t], negative_slope)  # [E,H]
+    idx = dst_t[:, None].expand(-1, heads)
+    m = torch.full((n, heads), -torch.inf, dtype=e.dtype).scatter_reduce(0, idx, e.detach(), "amax",
+                                                                         include_self=True)
+    p = torch.exp(e - m[dst_t])
+    denom = torch.zeros(n, heads, dtype=e.dtype).index_add_(0, dst_t, p)
+    a = p / denom[dst_t]
+    out = torch.zeros(n, heads, d, dtype=ft.dtype).index_add_(0, dst_t, a[:, :, None] * ft[src_t])
+    if residual:
+        res = x if res_weight is None else x @ res_weight.t()
+        out = out + res.view(n, heads, d)
+    if bias is not None:
+        out = out + bias.view(1, heads, d)
+    if act == "relu":
+        out = torch.relu(out)
+    elif act == "leaky_relu":
+        out = torch.nn.functional.leaky_relu(out, slope)
+    return out, a[:, :, None]
+
+
 def evolve_gcn_o_torch(snapshots, n, x, init_weights, grus, biases, act="leaky_relu",
                        detach_state=True):
     """EvolveGCN-O over a list of snapshots [(src, dst), ...] in differentiable torch ops.

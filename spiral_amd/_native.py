@@ -50,6 +50,14 @@ _SIGNATURES = {
     "spmi_rnn_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
                                   c_vp]),
     "spmi_rnn_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "spmi_gat_edge_softmax": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp,
+                                      c_vp, c_i32, c_i32, c_vp]),
+    "spmi_gat_edge_softmax_bwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp,
+                                          c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spmi_segment_sum": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spmi_sddmm_dot_supported": (c_int, [c_i32, c_i32]),
+    "spmi_sddmm_dot": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                               c_vp, c_vp]),
     "spmi_cell_fused_supported": (c_int, [c_i64, c_i64]),
     "spmi_cell_fused_fwd": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -7,9 +7,10 @@ from torch.nn import Module as MLBaseModel
 from torch.nn import Sequential as Sequential
 
 from spiral_amd.core.commonF import nt_layers_list
+from spiral_amd.nn.gatconv import GATConv
 from spiral_amd.nn.graphconv import GraphConv
 from spiral_amd.nn.sageconv import SAGEConv
 from spiral_amd.nn.sgconv import SGConv
 
 __all__ = ["Tensor", "Dropout", "MLBaseModel", "Sequential", "nt_layers_list", "GraphConv", "SGConv",
-           "SAGEConv"]
+           "SAGEConv", "GATConv"]

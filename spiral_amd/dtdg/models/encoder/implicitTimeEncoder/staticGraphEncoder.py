@@ -1,15 +1,17 @@
 """Static graph encoders applied to one snapshot at a time; API of
 spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:35-117.
 
-GCN is the encoder on the accelerated path; SGCN and GraphSage ('gcn' aggregator) sit on
-the same aggregation kernel.  GAT (edge softmax) is not provided.
+GCN is the encoder on the accelerated path; SGCN, GraphSage ('gcn' aggregator) and GAT sit
+on the same aggregation kernel (GAT adds the edge-softmax kernels).
 """
 from abc import abstractmethod
+import logging
 from typing import List, Tuple
 
 import torch.nn.functional as F
 
-from spiral_amd.core.types import GraphConv, MLBaseModel, SAGEConv, SGConv, Tensor, nt_layers_list
+from spiral_amd.core.types import (GATConv, GraphConv, MLBaseModel, SAGEConv, SGConv, Tensor,
+                                   nt_layers_list)
 from spiral_amd.dtdg.types import Snapshot
 
 
@@ -70,6 +72,32 @@ class SGCN(StaticGraphEncoder):
     def forward(self, in_sample: Tuple[Snapshot, List], training: bool = False) -> Tuple[Tensor, List]:
         snapshot, dst_node_ids = in_sample
         h = self.layers[0](snapshot.observation, snapshot.node_feature())
+        return (h, dst_node_ids)
+
+
+class GAT(StaticGraphEncoder):
+    """One GATConv per entry of `heads`; self-loops are added to the snapshot and the heads
+    of a layer are concatenated (staticGraphEncoder.py:155-192)."""
+
+    def __init__(self, heads: List[int], in_feat: int, n_hidden: int, **kwargs):
+        super().__init__()
+        self.n_layers = len(heads)
+        self.heads = heads
+        self.n_hidden = n_hidden
+        if heads[-1] > 1:
+            logging.getLogger(__name__).warning(
+                "The head of attention for the last layer is %d which is greater than 1, the output "
+                "dimension will be %d", heads[-1], heads[-1] * n_hidden)
+        self.layers.append(GATConv(in_feat, n_hidden, heads[0], **kwargs))
+        for i in range(1, self.n_layers):
+            self.layers.append(GATConv(n_hidden * heads[i - 1], n_hidden, heads[i], **kwargs))
+
+    def forward(self, in_sample: Tuple[Snapshot, List], training=False) -> Tuple[Tensor, List]:
+        snapshot, dst_node_ids = in_sample
+        g = snapshot.observation.add_self_loop()
+        h = snapshot.node_feature()
+        for i in range(self.n_layers):
+            h = self.layers[i](g, h).reshape(-1, self.heads[i] * self.n_hidden)
         return (h, dst_node_ids)
 
 

@@ -406,6 +406,7 @@ class SnapshotGraph(NormalisedAdjacency):
         self._csr = self._csr_t = self._out_deg = None
         self._norms = {}
         self._edge_scales = {}
+        self._t2f = None
 
     def successors(self, v: int) -> torch.Tensor:
         """Destination ids of the edges leaving node v, in edge order."""

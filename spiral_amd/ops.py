@@ -85,6 +85,117 @@ def gcn_aggregate(g, x: torch.Tensor, norm: str = "both", bias: Optional[torch.T
     return GcnAggregate.apply(x, bias, g, norm, edge_weight, act, slope)
 
 
+# --------------------------------------------------------------------------- attention
+def _heavy(csr):
+    return nv.ptr(csr.heavy_rows), csr.n_heavy, csr.heavy_thresh
+
+
+def edge_softmax_scores(csr, el: torch.Tensor, er: torch.Tensor, slope: float, keep_raw: bool):
+    """attn[h, j] = softmax over the entries j of a row of LeakyReLU(el[src_j, h] + er[row, h]);
+    returns (attn, raw) head-major [H, E] in CSR order (raw = logits before LeakyReLU)."""
+    nv.require_cuda(el, er)
+    heads = el.shape[1]
+    attn = torch.empty(heads, csr.nnz, dtype=torch.float32, device=el.device)
+    raw = torch.empty_like(attn) if keep_raw else None
+    with torch.cuda.device(el.device):
+        nv.check(nv.lib().spmi_gat_edge_softmax(
+            nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.nnz, nv.ptr(el), nv.ptr(er),
+            heads, float(slope), nv.ptr(attn), nv.ptr(raw), *_heavy(csr), nv.stream()),
+            "spmi_gat_edge_softmax")
+    return attn, raw
+
+
+def _csr_to_csr_t_positions(g) -> torch.Tensor:
+    """For every position of the by-source CSR, the position of the same edge in the
+    by-destination CSR (cached on the graph)."""
+    perm = getattr(g, "_t2f", None)
+    if perm is None:
+        csr, csr_t = g.csr(want_eid=True), g.csr_t(want_eid=True)
+        inv = torch.empty(csr.nnz, dtype=torch.int64, device=csr.eid.device)
+        inv[csr.eid.long()] = torch.arange(csr.nnz, device=csr.eid.device)
+        perm = g._t2f = inv[csr_t.eid.long()]
+    return perm
+
+
+class GatAggregate(torch.autograd.Function):
+    """out[v, h, :] = act(sum_{u->v} a_uv^h ft[u, h, :] + bias) with a = edge softmax of
+    LeakyReLU(el[u] + er[v]) over the incoming edges of v (dgl GATConv.forward between its
+    dense projections).  ft [N, H*D], el / er [N, H]."""
+
+    @staticmethod
+    def forward(ctx, ft, el, er, bias, g, heads, slope, act, act_slope):
+        csr = g.csr()
+        n, width = ft.shape
+        d = width // heads
+        need_grad = any(ctx.needs_input_grad[:3])
+        ft_c, el_c, er_c = ft.detach().contiguous(), el.detach().contiguous(), er.detach().contiguous()
+        attn, raw = edge_softmax_scores(csr, el_c, er_c, slope, need_grad)
+        out = torch.empty(csr.n_rows, width, dtype=torch.float32, device=ft.device)
+        b = None if bias is None else bias.detach()
+        for h in range(heads):
+            cols = slice(h * d, (h + 1) * d)
+            aggregate(csr, ft_c[:, cols], None, attn[h], None, None if b is None else b[cols], act,
+                      act_slope, out=out[:, cols])
+        ctx.g, ctx.heads, ctx.slope, ctx.act, ctx.act_slope = g, heads, slope, act, act_slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(ft_c, attn, raw, out if act not in (None, "none") else None)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        ft, attn, raw, out = ctx.saved_tensors
+        g, heads = ctx.g, ctx.heads
+        need_b = ctx.needs_input_grad[3] and ctx.has_bias
+        g_p, g_b = g_out.contiguous(), None
+        if out is not None or need_b:
+            g_p, g_b = _act_bias_bwd(g_p, out if out is not None else g_p, ctx.act, ctx.act_slope,
+                                     need_b)
+        csr, csr_t = g.csr(), g.csr_t()
+        t2f = _csr_to_csr_t_positions(g)
+        csr, csr_t = g.csr(), g.csr_t()  # the calls above may have rebuilt them with edge ids
+        n_src, width = ft.shape
+        d = width // heads
+        lib = nv.lib()
+        if not lib.spmi_sddmm_dot_supported(heads, d):
+            raise nv.SpmiError(f"attention backward needs a head width that is a power of two below "
+                               f"64 or a multiple of 64 (got {d}) and heads*width <= 512")
+        # gradient of the projected source rows through the weighted sum
+        attn_t = attn.index_select(1, t2f)
+        g_ft = torch.empty_like(ft)
+        for h in range(heads):
+            cols = slice(h * d, (h + 1) * d)
+            aggregate(csr_t, g_p[:, cols], None, attn_t[h], None, None, None, out=g_ft[:, cols])
+        with torch.cuda.device(ft.device):
+            d_attn = torch.empty_like(attn)
+            nv.check(lib.spmi_sddmm_dot(nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.nnz,
+                                        nv.ptr(g_p), g_p.stride(0), nv.ptr(ft), ft.stride(0), heads, d,
+                                        nv.ptr(d_attn), nv.stream()), "spmi_sddmm_dot")
+            d_raw = torch.empty_like(attn)
+            g_er = torch.empty(csr.n_rows, heads, dtype=torch.float32, device=ft.device)
+            nv.check(lib.spmi_gat_edge_softmax_bwd(
+                nv.ptr(csr.indptr), csr.n_rows, csr.nnz, nv.ptr(attn), nv.ptr(raw), nv.ptr(d_attn),
+                heads, float(ctx.slope), nv.ptr(d_raw), nv.ptr(g_er), *_heavy(csr), nv.stream()),
+                "spmi_gat_edge_softmax_bwd")
+            d_raw_t = d_raw.index_select(1, t2f)
+            g_el = torch.empty(n_src, heads, dtype=torch.float32, device=ft.device)
+            nv.check(lib.spmi_segment_sum(nv.ptr(csr_t.indptr), csr_t.n_rows, csr_t.nnz,
+                                          nv.ptr(d_raw_t), heads, nv.ptr(g_el), *_heavy(csr_t),
+                                          nv.stream()), "spmi_segment_sum")
+        return g_ft, g_el, g_er, g_b, None, None, None, None, None
+
+
+def gat_aggregate(g, ft: torch.Tensor, el: torch.Tensor, er: torch.Tensor, heads: int,
+                  negative_slope: float = 0.2, bias: Optional[torch.Tensor] = None,
+                  act: Optional[str] = None, act_slope: float = 0.01):
+    """Differentiable attention aggregation; returns (out [N, H*D], attn [H, E] in the order
+    of g.csr())."""
+    nv.require_cuda(ft, el, er, bias)
+    if ft.dtype != torch.float32 or ft.dim() != 2 or ft.shape[1] % heads:
+        raise nv.SpmiError(f"gat_aggregate expects float32 [N, heads*D] features, got {tuple(ft.shape)}")
+    return GatAggregate.apply(ft, el, er, bias, g, heads, float(negative_slope), act, float(act_slope))
+
+
 # --------------------------------------------------------------------------- recurrent cells
 def _rows(mem: torch.Tensor, ids: Optional[torch.Tensor], m: int) -> torch.Tensor:
     """Dense [M,H] view/copy of the memory rows a batch reads (GEMM operand)."""
