@@ -284,6 +284,22 @@ int spmi_sddmm_dot(const int32_t* indptr, const int32_t* indices, int64_t n_rows
                    const float* A, int64_t lda, const float* B, int64_t ldb, int32_t H, int32_t D,
                    float* out /*[H,E]*/, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Weight-gradient GEMM: C[M,N] (+)= A[K,M]^T B[K,N], row-major, K = number
+ * of nodes, M and N = layer widths (<= 4096).  Replaces the library GEMM that
+ * autograd runs for dW = X^T dY of every dense layer on the path in the
+ * training loop (examples/torch/citation_prediction.py:96-100): GraphConv's
+ * weight (staticGraphEncoder.py:113,116), the gate weights of nn.GRU/LSTM/RNN
+ * (implicitTimeModels.py:185-187,256-258,284-286), the MLP's Linear layers
+ * (simpleDecoder.py:60-72).  Exact fp32 products and sums on the matrix
+ * cores; K is split over the grid and the partial blocks are summed in a
+ * fixed order (bit-reproducible).  accumulate != 0 adds to C.
+ * ---------------------------------------------------------------------- */
+size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int spmi_gemm_tn(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/, int64_t ldb,
+                 int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc, int accumulate,
+                 void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

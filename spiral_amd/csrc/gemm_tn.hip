@@ -1,0 +1,218 @@
+// Weight-gradient GEMM for gfx950: C[M,N] = A[K,M]^T B[K,N] with K = number of nodes
+// (millions) and M, N = layer widths (tens to hundreds).
+//
+// What it replaces in the reference: the autograd of every dense layer on the path,
+// dW = X^T dY, which torch evaluates with a library GEMM: GraphConv's weight
+// (dgl GraphConv.forward, call sites staticGraphEncoder.py:113,116), the gate weights of
+// nn.GRU / nn.LSTM / nn.RNN (implicitTimeModels.py:185-187,256-258,284-286) and the MLP's
+// Linear layers (simpleDecoder.py:60-72) in the training loop of
+// examples/torch/citation_prediction.py:96-100.  The library kernels are tiled for square
+// problems and run this shape (tiny output, huge reduction) at a few percent of peak.
+//
+// Design: the reduction dimension is split over the grid.  A wave owns a 32 x (32*NT)
+// block of C and a chunk of K; for the fp32 matrix instruction v_mfma_f32_32x32x2_f32 the
+// operand layouts are "lane l holds A^T[m = l%32][k = l/32]" and "B[k = l/32][n = l%32]",
+// which for row-major A[K,M] and B[K,N] are exactly two coalesced 128-byte row segments:
+// operands stream from global memory straight into the matrix cores, no LDS, no
+// transposition.  Eight k-pairs of loads are kept in flight.  Per-chunk partial blocks go
+// to a workspace and a second kernel sums them in chunk order: fixed order, bit-reproducible,
+// no atomics.  Exact fp32 products and fp32 accumulation (not a reduced-precision format).
+// Bound: MFMA for wide outputs (2*K*M*N flop), HBM (K*(M+N)*4 bytes) for narrow ones.
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kUnroll = 8;  // k-pairs per loop trip (16 rows of A and B)
+
+template <int NT>
+__global__ __launch_bounds__(kThreads) void gemm_tn_partial_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
+    int M, int N, int64_t k_chunk, float* __restrict__ partial, int m_strips, int n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int st = static_cast<int>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  if (st >= m_strips * n_tiles) return;
+  const int m0 = (st % m_strips) * 32;
+  const int n0 = (st / m_strips) * 32 * NT;
+  const int64_t k_begin = static_cast<int64_t>(blockIdx.y) * k_chunk;
+  const int64_t k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // Out-of-range columns read a valid column and are zeroed after the load, so that every
+  // load is unconditional (a predicated load would serialise the loads in flight).
+  // Addresses are "wave-uniform row base + 32-bit lane offset": one offset register per
+  // operand column, the row bases live in scalar registers.
+  const bool a_ok = m0 + lr < M;
+  const uint32_t a_off = static_cast<uint32_t>(lh * lda + (a_ok ? m0 + lr : 0));
+  bool b_ok[NT];
+  uint32_t b_off[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    b_ok[t] = n0 + 32 * t + lr < N;
+    b_off[t] = static_cast<uint32_t>(lh * ldb + (b_ok[t] ? n0 + 32 * t + lr : 0));
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+  int64_t k = k_begin;
+  for (; k + 2 * kUnroll <= k_end; k += 2 * kUnroll) {
+    float a[kUnroll], b[kUnroll][NT];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float* a_row = A + (k + 2 * u) * lda;
+      const float* b_row = B + (k + 2 * u) * ldb;
+      a[u] = a_row[a_off];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[u][t] = b_row[b_off[t]];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float av = a_ok ? a[u] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ok[t] ? b[u][t] : 0.0f, acc[t], 0, 0, 0);
+    }
+  }
+  for (; k < k_end; k += 2) {  // tail of the chunk: rows past k_end contribute zero
+    const bool r_ok = k + lh < k_end;
+    const int64_t kk = r_ok ? k : k - 1;  // k >= k_begin + 1 when lh == 1 overruns; stays inside
+    const float av = (a_ok && r_ok) ? (A + kk * lda)[a_off] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float bv = (b_ok[t] && r_ok) ? (B + kk * ldb)[b_off[t]] : 0.0f;
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+
+  float* out = partial + static_cast<size_t>(blockIdx.y) * M * N;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 32 * t + lr;
+    if (n >= N) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < M) out[static_cast<size_t>(m) * N + n] = acc[t][e];
+    }
+  }
+}
+
+// C = (accumulate ? C : 0) + sum over chunks.  L lanes share one output element: lane c of
+// the group adds chunks c, c+L, ... and the group is folded by a shuffle tree, so the order
+// of additions is fixed by the shape alone.  Inside a wave the 64/L elements are the fast
+// index (neighbouring lanes read neighbouring addresses).
+template <int L>
+__global__ __launch_bounds__(kThreads) void gemm_tn_reduce_kernel(const float* __restrict__ partial,
+                                                                  int n_chunks, int64_t mn, int N,
+                                                                  float* __restrict__ C, int64_t ldc,
+                                                                  int accumulate) {
+  constexpr int EPW = 64 / L;  // elements per wave
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  const int64_t i = wave * EPW + (lane % EPW);
+  const int cl = lane / EPW;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < mn) {
+    int c = cl;
+    for (; c + L < n_chunks; c += 2 * L) {  // two independent loads per trip
+      s0 += partial[static_cast<size_t>(c) * mn + i];
+      s1 += partial[static_cast<size_t>(c + L) * mn + i];
+    }
+    if (c < n_chunks) s0 += partial[static_cast<size_t>(c) * mn + i];
+  }
+  float s = s0 + s1;
+#pragma unroll
+  for (int off = 32; off >= EPW; off >>= 1) s += __shfl_xor(s, off);
+  if (i < mn && cl == 0) {
+    float* dst = C + (i / N) * ldc + (i % N);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+struct Shape {
+  int nt;         // 32-column tiles per wave
+  int m_strips;   // ceil(M / 32)
+  int n_tiles;    // ceil(N / (32 * nt))
+  int n_chunks;   // pieces of K
+  int64_t k_chunk;
+};
+
+Shape plan(int64_t M, int64_t N, int64_t K) {
+  Shape s{};
+  s.nt = N > 64 ? 4 : (N > 32 ? 2 : 1);
+  s.m_strips = static_cast<int>((M + 31) / 32);
+  s.n_tiles = static_cast<int>((N + 32 * s.nt - 1) / (32 * s.nt));
+  const int64_t blocks = s.m_strips * s.n_tiles;
+  // about eight waves per SIMD over the whole chip, at least 256 rows of K per wave
+  int64_t chunks = 8192 / blocks;
+  const int64_t max_chunks = (K + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  s.k_chunk = ((K + chunks - 1) / chunks + 15) / 16 * 16;
+  s.n_chunks = static_cast<int>((K + s.k_chunk - 1) / s.k_chunk);
+  return s;
+}
+
+int check_gemm_tn(int64_t M, int64_t N, int64_t K) {
+  SPMI_REQUIRE(M >= 1 && N >= 1 && K >= 1 && M <= 4096 && N <= 4096 && K < (int64_t{1} << 40),
+               SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: bad sizes M=%lld N=%lld K=%lld (M, N <= 4096)",
+               (long long)M, (long long)N, (long long)K);
+  return SPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < 1 || M > 4096 || N > 4096) return 0;
+  const Shape s = plan(M, N, K);
+  return sizeof(float) * static_cast<size_t>(s.n_chunks) * M * N;
+}
+
+int spmi_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t M,
+                 int64_t N, float* C, int64_t ldc, int accumulate, void* ws, size_t ws_bytes,
+                 void* stream) {
+  if (int rc = check_gemm_tn(M, N, K)) return rc;
+  SPMI_REQUIRE(A && B && C && ws, SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: null pointer argument");
+  SPMI_REQUIRE(lda >= M && ldb >= N && ldc >= N, SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_tn: leading dimensions (%lld,%lld,%lld) too small", (long long)lda,
+               (long long)ldb, (long long)ldc);
+  SPMI_REQUIRE(ws_bytes >= spmi_gemm_tn_workspace_bytes(M, N, K), SPMI_ERR_WORKSPACE,
+               "spmi_gemm_tn: workspace %zu < required %zu", ws_bytes,
+               spmi_gemm_tn_workspace_bytes(M, N, K));
+  const Shape s = plan(M, N, K);
+  hipStream_t st = spmi::as_stream(stream);
+  float* partial = static_cast<float*>(ws);
+  const dim3 grid((s.m_strips * s.n_tiles + kWaves - 1) / kWaves, s.n_chunks);
+#define SPMI_GEMM_TN(NT)                                                                        \
+  gemm_tn_partial_kernel<NT><<<grid, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N,     \
+                                                        s.k_chunk, partial, s.m_strips, s.n_tiles)
+  if (s.nt == 4) SPMI_GEMM_TN(4);
+  else if (s.nt == 2) SPMI_GEMM_TN(2);
+  else SPMI_GEMM_TN(1);
+#undef SPMI_GEMM_TN
+  SPMI_CHECK_LAUNCH("gemm_tn_partial");
+  const int64_t mn = M * N;
+  if (s.n_chunks >= 64) {
+    const unsigned blocks = static_cast<unsigned>((mn + 4 * kWaves - 1) / (4 * kWaves));
+    gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(partial, s.n_chunks, mn, (int)N, C, ldc,
+                                                           accumulate);
+  } else {
+    const unsigned blocks = static_cast<unsigned>((mn + kThreads - 1) / kThreads);
+    gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(partial, s.n_chunks, mn, (int)N, C, ldc,
+                                                          accumulate);
+  }
+  SPMI_CHECK_LAUNCH("gemm_tn_reduce");
+  return SPMI_OK;
+}
+
+}  // extern "C"

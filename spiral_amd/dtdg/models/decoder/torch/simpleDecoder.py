@@ -6,6 +6,8 @@ from typing import List, Tuple
 import torch
 from torch import nn
 
+from spiral_amd.nn.linear import TallLinear
+
 
 class SimpleDecoder(nn.Module):
     def __init__(self):
@@ -37,10 +39,10 @@ class MLP(SimpleDecoder):
             raise ValueError(f"unsupported activation {activation!r}")
         width = input_dim
         for embed_dim in embed_dims:
-            self.layers.extend([nn.Linear(width, embed_dim), nn.BatchNorm1d(embed_dim), nn.ReLU(),
+            self.layers.extend([TallLinear(width, embed_dim), nn.BatchNorm1d(embed_dim), nn.ReLU(),
                                 nn.Dropout(p=dropout)])
             width = embed_dim
-        self.layers.append(nn.Linear(width, output_dim))
+        self.layers.append(TallLinear(width, output_dim))
         if _ACTIVATIONS[activation] is not None:
             self.layers.append(_ACTIVATIONS[activation]())
         self.mlp = nn.Sequential(*self.layers)

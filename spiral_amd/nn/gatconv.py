@@ -16,6 +16,7 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
+from spiral_amd.nn.linear import TallLinear
 from spiral_amd.nn.graphconv import _classify_activation
 from spiral_amd.ops import gat_aggregate
 
@@ -32,7 +33,7 @@ class GATConv(nn.Module):
         self._out_feats = out_feats
         self._allow_zero_in_degree = allow_zero_in_degree
         self._negative_slope = negative_slope
-        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.fc = TallLinear(in_feats, out_feats * num_heads, bias=False)
         self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
         self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
         self.feat_drop = nn.Dropout(feat_drop)
@@ -42,7 +43,7 @@ class GATConv(nn.Module):
             self.register_parameter("bias", None)
         if residual:
             if in_feats != out_feats * num_heads:
-                self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=False)
+                self.res_fc = TallLinear(in_feats, num_heads * out_feats, bias=False)
             else:
                 self.res_fc = nn.Identity()
         else:

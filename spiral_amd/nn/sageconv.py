@@ -14,6 +14,7 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
+from spiral_amd.nn.linear import TallLinear
 from spiral_amd.ops import gcn_aggregate
 
 
@@ -32,7 +33,7 @@ class SAGEConv(nn.Module):
         self.norm = norm
         self.feat_drop = nn.Dropout(feat_drop)
         self.activation = activation
-        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=False)
+        self.fc_neigh = TallLinear(in_feats, out_feats, bias=False)
         if bias:
             self.bias = nn.Parameter(torch.zeros(out_feats))
         else:

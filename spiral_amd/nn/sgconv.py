@@ -14,6 +14,7 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
+from spiral_amd.nn.linear import TallLinear
 from spiral_amd.ops import gcn_aggregate
 
 
@@ -21,7 +22,7 @@ class SGConv(nn.Module):
     def __init__(self, in_feats: int, out_feats: int, k: int = 1, cached: bool = False, bias: bool = True,
                  norm=None, allow_zero_in_degree: bool = False):
         super().__init__()
-        self.fc = nn.Linear(in_feats, out_feats, bias=bias)
+        self.fc = TallLinear(in_feats, out_feats, bias=bias)
         self._cached = cached
         self._cached_h: Optional[torch.Tensor] = None
         self._k = k

@@ -1,0 +1,72 @@
+"""The weight-gradient GEMM C = A^T B (split-K on the fp32 matrix cores) against float64
+numpy: fp32 products and sums, so 1e-5 relative to the sum of absolute terms."""
+import numpy as np
+import pytest
+import torch
+
+from spiral_amd import _native as nv
+from spiral_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,m,n", [
+    (16384, 128, 128), (20001, 128, 384), (50_000, 10, 128), (33_333, 20, 10), (17_000, 5, 1),
+    (16_400, 33, 65), (100_000, 256, 512), (16385, 1, 1),
+])
+def test_gemm_tn_matches_float64(dev, k, m, n):
+    rng = np.random.default_rng(k + m + n)
+    a = rng.standard_normal((k, m)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    got = ops.gemm_tn(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+    assert got.shape == (m, n)
+    assert (np.abs(got - want) / scale).max() < 1e-5
+    again = ops.gemm_tn(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    assert np.array_equal(got, again)  # fixed summation order
+
+
+def test_gemm_tn_strided_operands_and_accumulate(dev):
+    k, m, n = 40_000, 48, 96
+    big_a = torch.randn(k, 3 * m, device=dev)
+    big_b = torch.randn(k, 2 * n, device=dev)
+    a, b = big_a[:, m:2 * m], big_b[:, n:]           # column slices: leading dimension > width
+    want = a.double().t() @ b.double()
+    got = ops.gemm_tn(a, b)
+    assert (got.double() - want).abs().max() / want.abs().max() < 1e-5
+    lib = nv.lib()
+    c = torch.ones(m, n, device=dev)
+    nbytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    nv.check(lib.spmi_gemm_tn(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n, nv.ptr(c), n, 1,
+                              nv.ptr(ws), nbytes, nv.stream()), "spmi_gemm_tn")
+    assert (c.double() - 1 - want).abs().max() / want.abs().max() < 1e-5
+    with pytest.raises(nv.SpmiError):
+        nv.check(lib.spmi_gemm_tn(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n, nv.ptr(c), n, 0,
+                                  nv.ptr(ws), 16, nv.stream()), "spmi_gemm_tn")
+
+
+def test_dense_layers_use_it_and_keep_their_gradients(dev):
+    """TallLinear / rows_times_weight: same forward as torch, gradients within 1e-5."""
+    from spiral_amd.nn.linear import TallLinear
+
+    k = 30_000
+    torch.manual_seed(0)
+    lin = TallLinear(24, 40).to(dev)
+    ref = torch.nn.Linear(24, 40).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(k, 24, device=dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    wgt = torch.randn(k, 40, device=dev)
+    (lin(xa) * wgt).sum().backward()
+    (ref(xb) * wgt).sum().backward()
+    rel = lambda p, q: ((p - q).abs().max() / q.abs().max()).item()
+    assert rel(xa.grad, xb.grad) < 1e-5
+    assert rel(lin.weight.grad, ref.weight.grad) < 1e-5
+    assert rel(lin.bias.grad, ref.bias.grad) < 1e-5
+    w = torch.randn(24, 40, device=dev)
+    wa, wb = w.clone().requires_grad_(), w.clone().requires_grad_()
+    (ops.rows_times_weight(x, wa) * wgt).sum().backward()
+    ((x @ wb) * wgt).sum().backward()
+    assert rel(wa.grad, wb.grad) < 1e-5
