@@ -278,7 +278,7 @@ int spmi_segment_sum(const int32_t* indptr, int64_t n_rows, int64_t E, const flo
                      int32_t n_heavy, int32_t heavy_thresh, void* stream);
 /* out[h,j] = <A[row(j), h*D:(h+1)*D], B[indices[j], h*D:(h+1)*D]>: gradient of the
  * attention weights, A = d(output) rows of destinations, B = projected source rows.
- * D must be a power of two below 64 or a multiple of 64, H*D <= 512. */
+ * D must be a power of two below 64 or a multiple of 64, H <= 8, H*D <= 512. */
 int spmi_sddmm_dot_supported(int32_t H, int32_t D);
 int spmi_sddmm_dot(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t E,
                    const float* A, int64_t lda, const float* B, int64_t ldb, int32_t H, int32_t D,

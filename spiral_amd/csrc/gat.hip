@@ -99,27 +99,50 @@ __global__ __launch_bounds__(G == kHeavy ? kHeavy : kLightBlock) void gat_softma
   int32_t r, lo, hi;
   int lane_g;
   const bool valid = pick_row<G>(indptr, n_rows, heavy_rows, heavy_thresh, &r, &lo, &hi, &lane_g);
+  // Two passes per head.  Pass 1 gathers the logits (four independent gathers per lane in
+  // flight), stores the scores and keeps a running (max, sum of exp) per lane, merged over
+  // the group afterwards; pass 2 normalises.  The first score of every lane stays in a
+  // register, so rows of up to G entries never read back what they wrote.
+  const int32_t j_first = lo + lane_g;
   for (int h = 0; h < H; ++h) {
     float* a = attn + static_cast<size_t>(h) * E;
     const float erh = valid ? er[static_cast<size_t>(r) * H + h] : 0.f;
-    float m = -FLT_MAX;
-    for (int32_t j = lo + lane_g; j < hi; j += G) {
-      const float x = el[static_cast<size_t>(indices[j]) * H + h] + erh;
-      if (raw) raw[static_cast<size_t>(h) * E + j] = x;
-      const float s = x > 0.f ? x : x * slope;
-      a[j] = s;
-      m = fmaxf(m, s);
+    float m = -FLT_MAX, l = 0.f, s_first = 0.f;
+    constexpr int kBatch = G == kHeavy ? 8 : 4;
+    for (int32_t j = j_first; j < hi; j += kBatch * G) {
+      float x[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        const int32_t jj = j + q * G;
+        x[q] = jj < hi ? el[static_cast<size_t>(indices[jj]) * H + h] + erh : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        const int32_t jj = j + q * G;
+        if (jj >= hi) break;
+        if (raw) raw[static_cast<size_t>(h) * E + jj] = x[q];
+        const float sc = x[q] > 0.f ? x[q] : x[q] * slope;
+        if (jj == j_first) s_first = sc; else a[jj] = sc;
+        if (sc > m) {
+          l = l * expf(m - sc) + 1.0f;
+          m = sc;
+        } else {
+          l += expf(sc - m);
+        }
+      }
     }
-    m = group_max<G>(m, s_red);
-    float l = 0.f;
-    for (int32_t j = lo + lane_g; j < hi; j += G) {
-      const float p = expf(a[j] - m);
-      a[j] = p;
-      l += p;
+    const float big = group_max<G>(m, s_red);
+    const float total = group_sum<G>(l * expf(m - big), s_red);
+    const float inv = 1.0f / total;
+    if (j_first < hi) a[j_first] = expf(s_first - big) * inv;
+    for (int32_t j = j_first + G; j < hi; j += 4 * G) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (j + q * G < hi) ? a[j + q * G] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q * G < hi) a[j + q * G] = expf(v[q] - big) * inv;
     }
-    l = group_sum<G>(l, s_red);
-    const float inv = 1.0f / l;
-    for (int32_t j = lo + lane_g; j < hi; j += G) a[j] *= inv;
   }
 }
 
@@ -180,6 +203,7 @@ __global__ __launch_bounds__(G == kHeavy ? kHeavy : kLightBlock) void segment_su
 // 64-feature tiles (D a multiple of 64).
 constexpr int kEdgesPerWave = 256;
 constexpr int kSddmmBlock = 256;
+constexpr int kSddmmMaxHeads = 8;
 
 template <int T>
 __global__ __launch_bounds__(kSddmmBlock) void sddmm_dot_kernel(
@@ -192,61 +216,89 @@ __global__ __launch_bounds__(kSddmmBlock) void sddmm_dot_kernel(
   if (j0 >= E) return;
   const int64_t j1 = (j0 + kEdgesPerWave < E) ? j0 + kEdgesPerWave : E;
   const int32_t F = H * D;
-  // largest r with indptr[r] <= j0
-  int32_t lo = 0, hi = n_rows - 1;
-  while (lo < hi) {
-    const int32_t m = lo + ((hi - lo + 1) >> 1);
-    if (indptr[m] <= j0) lo = m; else hi = m - 1;
-  }
-  int32_t r = lo;
-  int64_t row_end = indptr[r + 1];
-  float a[T];
-  bool have = false;
   const int seg = D < 64 ? D : 64;  // lanes that share a head inside one 64-feature tile
-  for (int64_t j = j0; j < j1; ++j) {
-    while (j >= row_end) {
-      ++r;
-      row_end = indptr[r + 1];
-      have = false;
+  const int tiles_per_head = D >= 64 ? D / 64 : 1;
+  // first row of the wave: largest r with indptr[r] <= j0 (skips empty rows)
+  int32_t r_first = 0;
+  {
+    int32_t lo = 0, hi = n_rows - 1;
+    while (lo < hi) {
+      const int32_t m = lo + ((hi - lo + 1) >> 1);
+      if (indptr[m] <= j0) lo = m; else hi = m - 1;
     }
-    if (!have) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int f = lane + 64 * t;
-        a[t] = f < F ? A[static_cast<size_t>(r) * lda + f] : 0.f;
+    r_first = lo;
+  }
+  // per-wave staging of the 64 results of a group (per head), stored coalesced afterwards
+  __shared__ float s_out[kSddmmBlock / 64][kSddmmMaxHeads][64];
+  float(*stage)[64] = s_out[threadIdx.x >> 6];
+  float a[T];
+  int32_t cur = -1;
+  for (int64_t base = j0; base < j1; base += 64) {
+    // one coalesced load of 64 neighbour ids; every lane finds the row of its own edge
+    const int64_t jl = base + lane;
+    const bool live = jl < j1;
+    const int32_t my_src = live ? indices[jl] : 0;
+    int32_t my_row = r_first;
+    if (live) {
+      int32_t lo = r_first, hi = n_rows - 1;
+      while (lo < hi) {
+        const int32_t m = lo + ((hi - lo + 1) >> 1);
+        if (indptr[m] <= jl) lo = m; else hi = m - 1;
       }
-      have = true;
+      my_row = lo;
     }
-    const float* brow = B + static_cast<size_t>(indices[j]) * ldb;
-    float p[T];
+    const int count = (j1 - base < 64) ? static_cast<int>(j1 - base) : 64;
+    for (int k4 = 0; k4 < count; k4 += 4) {
+      // four independent row gathers in flight before any of them is reduced
+      float p[4][T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int f = lane + 64 * t;
-      p[t] = f < F ? a[t] * brow[f] : 0.f;
-    }
-    if (D >= 64) {
-      // tiles of one head are summed first, then one wave reduction per head
-      const int tiles_per_head = D / 64;
+      for (int q = 0; q < 4; ++q) {
+        const int kk = (k4 + q < count) ? k4 + q : count - 1;
+        const float* brow = B + static_cast<size_t>(__builtin_amdgcn_readlane(my_src, kk)) * ldb;
 #pragma unroll
-      for (int t0 = 0; t0 < T; ++t0) {
-        if (t0 % tiles_per_head != 0 || t0 * 64 >= F) continue;
-        float v = 0.f;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          if (t >= t0 && t < t0 + tiles_per_head) v += p[t];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) out[static_cast<size_t>(t0 / tiles_per_head) * E + j] = v;
+        for (int t = 0; t < T; ++t) {
+          const int f = lane + 64 * t;
+          p[q][t] = brow[f < F ? f : 0];
+        }
       }
-    } else {
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        float v = p[t];
-        for (int off = seg / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        const int f = lane + 64 * t;
-        if (f < F && (lane % seg) == 0) out[static_cast<size_t>(f / D) * E + j] = v;
+      for (int q = 0; q < 4; ++q) {
+        if (k4 + q >= count) break;
+        const int32_t r = __builtin_amdgcn_readlane(my_row, k4 + q);
+        if (r != cur) {  // wave-uniform: the register copy of the destination row changes
+          cur = r;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const int f = lane + 64 * t;
+            a[t] = f < F ? A[static_cast<size_t>(r) * lda + f] : 0.f;
+          }
+        }
+        if (D >= 64) {
+          // tiles of one head are summed first, then one wave reduction per head
+#pragma unroll
+          for (int t0 = 0; t0 < T; ++t0) {
+            if (t0 % tiles_per_head != 0 || t0 * 64 >= F) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              if (t >= t0 && t < t0 + tiles_per_head) v += a[t] * p[q][t];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) stage[t0 / tiles_per_head][k4 + q] = v;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const int f = lane + 64 * t;
+            float v = f < F ? a[t] * p[q][t] : 0.f;
+            for (int off = seg / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (f < F && (lane % seg) == 0) stage[f / D][k4 + q] = v;
+          }
+        }
       }
     }
+    for (int h = 0; h < H; ++h)
+      if (lane < count) out[static_cast<size_t>(h) * E + base + lane] = stage[h][lane];
   }
 }
 
@@ -339,7 +391,7 @@ int spmi_segment_sum(const int32_t* indptr, int64_t n_rows, int64_t E, const flo
 }
 
 int spmi_sddmm_dot_supported(int32_t H, int32_t D) {
-  if (H < 1 || D < 1 || static_cast<int64_t>(H) * D > 512) return 0;
+  if (H < 1 || H > kSddmmMaxHeads || D < 1 || static_cast<int64_t>(H) * D > 512) return 0;
   if (D >= 64) return D % 64 == 0;
   return (D & (D - 1)) == 0;
 }
@@ -350,7 +402,7 @@ int spmi_sddmm_dot(const int32_t* indptr, const int32_t* indices, int64_t n_rows
   if (int rc = check_rows(n_rows, E, H, "spmi_sddmm_dot")) return rc;
   SPMI_REQUIRE(spmi_sddmm_dot_supported(H, D), SPMI_ERR_UNSUPPORTED,
                "spmi_sddmm_dot: head width D=%d must be a power of two below 64 or a multiple of "
-               "64, with H*D <= 512 (H=%d)", D, H);
+               "64, with H <= 8 and H*D <= 512 (H=%d)", D, H);
   const int64_t F = static_cast<int64_t>(H) * D;
   SPMI_REQUIRE(lda >= F && ldb >= F, SPMI_ERR_INVALID_ARG,
                "spmi_sddmm_dot: leading dimensions (%lld,%lld) smaller than H*D=%lld",
