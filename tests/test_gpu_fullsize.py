@@ -1,0 +1,144 @@
+"""The path at the full size of the headline workload (1M nodes, 10M edges, 128 features),
+where the CPU oracle cannot check every output in seconds: structural invariants of the CSR,
+size-independent algebraic properties of the aggregation (linearity, column checksums,
+adjointness of forward and backward), an independent library SpMM, determinism, and the
+oracle itself on a random sample of rows (rows are independent, so a sampled row is checked
+exactly as in the small tests)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from spiral_amd import graph as G
+from spiral_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+N, E, F = 1_000_000, 10_000_000, 128
+
+
+@pytest.fixture(scope="module")
+def big(dev):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    perm = torch.randperm(N, generator=gen, device=dev)
+    gen.manual_seed(1234)
+    u1 = torch.rand(E, generator=gen, device=dev, dtype=torch.float64)
+    u2 = torch.rand(E, generator=gen, device=dev, dtype=torch.float64)
+    dst = perm[(u1.pow_(3.0) * N).long().clamp_(max=N - 1)]
+    src = perm[(u2.pow_(1.5) * N).long().clamp_(max=N - 1)]
+    gen.manual_seed(7)
+    x = torch.randn(N, F, generator=gen, device=dev)
+    g = G.SnapshotGraph(src, dst, N)
+    yield dict(src=src, dst=dst, x=x, g=g)
+    torch.cuda.empty_cache()
+
+
+def test_csr_invariants_at_full_size(big):
+    src, dst, g = big["src"], big["dst"], big["g"]
+    for key, other, csr in ((dst, src, g.csr(want_eid=True)), (src, dst, g.csr_t(want_eid=True))):
+        indptr, eid = csr.indptr.long(), csr.eid.long()
+        assert indptr[0] == 0 and indptr[-1] == E
+        deg = indptr[1:] - indptr[:-1]
+        assert bool((deg >= 0).all())
+        assert torch.equal(deg, torch.bincount(key, minlength=N))       # degrees, independent count
+        rows = torch.repeat_interleave(torch.arange(N, device=key.device), deg)
+        assert torch.equal(key[eid], rows)                              # every entry sits in its row
+        assert torch.equal(other[eid], csr.indices.long())              # and carries the other endpoint
+        assert torch.equal(torch.sort(eid).values, torch.arange(E, device=key.device))  # a permutation
+        same_row = rows[1:] == rows[:-1]
+        assert bool((eid[1:][same_row] > eid[:-1][same_row]).all())     # stable inside a row
+        del rows, same_row
+    assert torch.equal(g.in_degrees(), torch.bincount(dst, minlength=N))
+    assert torch.equal(G.degree(src, N), torch.bincount(src, minlength=N))
+
+
+def test_aggregation_properties_at_full_size(big):
+    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    with torch.no_grad():
+        y = ops.gcn_aggregate(g, x, "both")
+        # determinism: the launch is reproducible bit for bit
+        assert torch.equal(y, ops.gcn_aggregate(g, x, "both"))
+        # linearity: A(2x - 3z) = 2 A x - 3 A z
+        z = torch.roll(x, 1, 0)
+        lhs = ops.gcn_aggregate(g, 2 * x - 3 * z, "both")
+        rhs = 2 * y - 3 * ops.gcn_aggregate(g, z, "both")
+        scale = ops.gcn_aggregate(g, 2 * x.abs() + 3 * z.abs(), "both")   # sum of absolute terms
+        assert ((lhs - rhs).abs() / scale.clamp_min(1e-30)).max() < 1e-5
+        # column checksum against an independent fp64 accumulation over the edge list:
+        # sum_v y[v] = sum_u x[u] * n_out[u] * (sum over out-edges of n_in[dst])
+        n_in = g.in_degrees().double().clamp_(min=1).rsqrt_()
+        n_out = torch.bincount(src, minlength=N).double().clamp_(min=1).rsqrt_()
+        col_w = torch.zeros(N, dtype=torch.float64, device=x.device).index_add_(0, src, n_in[dst]) * n_out
+        want = (x.double() * col_w[:, None]).sum(0)
+        ref_scale = (x.double().abs() * col_w[:, None]).sum(0)
+        assert ((y.double().sum(0) - want).abs() / ref_scale).max() < 1e-6
+        # adjointness of the forward and the backward aggregation: <A x, w> = <x, A^T w>
+        w = torch.randn_like(y)
+    xr = x.clone().requires_grad_()
+    (ops.gcn_aggregate(g, xr, "both") * w).sum().backward()
+    with torch.no_grad():
+        probe = torch.randn_like(x)
+        lhs = (ops.gcn_aggregate(g, probe, "both").double() * w.double()).sum()
+        rhs = (probe.double() * xr.grad.double()).sum()
+        assert abs(lhs - rhs) / (ops.gcn_aggregate(g, probe.abs(), "both").double() * w.double().abs()).sum() < 1e-6
+
+
+def test_aggregation_against_library_spmm_at_full_size(big):
+    """hipSPARSE through torch.sparse is an independent implementation of the same sum."""
+    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    csr = g.csr()
+    with torch.no_grad():
+        y = ops.gcn_aggregate(g, x, "none")
+        a = torch.sparse_csr_tensor(csr.indptr, csr.indices, torch.ones(E, device=x.device), size=(N, N))
+        want = a @ x
+        scale = a @ x.abs()
+        assert ((y - want).abs() / scale.clamp_min(1e-30)).max() < 1e-5
+
+
+def test_sampled_rows_against_the_oracle_at_full_size(big):
+    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    rng = np.random.default_rng(0)
+    deg = g.in_degrees()
+    hubs = torch.topk(deg, 3).indices.cpu().numpy()                 # chunked hub-row path
+    rows = np.unique(np.concatenate([rng.integers(0, N, 3000), hubs]))
+    rows_t = torch.from_numpy(rows).to(x.device)
+    keep = torch.isin(dst, rows_t)
+    s_k, d_k = src[keep].cpu().numpy(), dst[keep].cpu().numpy()
+    n_in = deg.double().clamp(min=1).rsqrt().float()
+    n_out = torch.bincount(src, minlength=N).double().clamp(min=1).rsqrt().float()
+    with torch.no_grad():
+        y = ops.gcn_aggregate(g, x, "both")[rows_t].cpu().numpy()
+    # the oracle on the sub-problem: the same edges, compacted to the sampled rows
+    local = np.searchsorted(rows, d_k)
+    xs = (x[torch.from_numpy(s_k).to(x.device)] * n_out[torch.from_numpy(s_k).to(x.device)][:, None]).cpu().numpy()
+    want = np.zeros((len(rows), F), dtype=np.float64)
+    np.add.at(want, local, xs.astype(np.float64))
+    absum = np.zeros_like(want)
+    np.add.at(absum, local, np.abs(xs).astype(np.float64))
+    scale_rows = n_in[rows_t].cpu().numpy().astype(np.float64)[:, None]
+    assert (np.abs(y - want * scale_rows) / np.maximum(absum * scale_rows, 1e-30)).max() < 1e-5
+
+
+def test_fused_gru_layer_at_full_size(big, dev):
+    """One recurrent layer over all nodes: the one-kernel path equals the library-GEMM +
+    gate-kernel path, and a row sample equals the CPU oracle (rows are independent)."""
+    x = big["x"]
+    torch.manual_seed(2)
+    gru = torch.nn.GRU(F, F, batch_first=True).to(dev)
+    w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
+    mem0 = torch.randn(N, F, device=dev)
+    with torch.no_grad():
+        mem_a, mem_b = mem0.clone(), mem0.clone()
+        h_a = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem_a)
+        ops.USE_FUSED_CELLS = False
+        try:
+            h_b = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem_b)
+        finally:
+            ops.USE_FUSED_CELLS = True
+        assert (h_a - h_b).abs().max() < 1e-5
+        assert torch.equal(h_a, mem_a) and torch.equal(h_b, mem_b)      # memory rows updated in place
+    rows = torch.from_numpy(np.random.default_rng(1).integers(0, N, 4096)).to(dev)
+    cpu = lambda t: t.detach().cpu().numpy()
+    want = orc.gru_cell(cpu(x[rows]), cpu(mem0[rows]), cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
+    assert np.abs(cpu(h_a[rows]) - want).max() < 1e-5
