@@ -37,7 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from spiral_amd import graph as G  # noqa: E402
+from spiral_amd import graph as G
+from spiral_amd import ops  # noqa: E402
 from spiral_amd import parallel as par  # noqa: E402
 from spiral_amd.core.types import GraphConv  # noqa: E402
 from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder.implicitTimeModels import GRU  # noqa: E402
@@ -467,6 +468,9 @@ def main():
                                 f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu), "
                                 f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
+                       "gate_gemm": ("fp32 results from bf16 matrix cores: operands split exactly in three "
+                                     "bf16 pieces, six piece products per term"
+                                     if ops.CELL_GEMM == "bf16x3" else "fp32 matrix instruction"),
                        "parallelism": (f"dst-row blocks x{world}, all-gather per layer" +
                                        (", layer-1 input replicated, layer-2 gather overlapped with the "
                                         "previous snapshot's recurrent update" if pipelined else "") +

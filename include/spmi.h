@@ -245,6 +245,20 @@ int spmi_cell_fused_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
                         float* c_out, int mem_write, float* saved, void* stream);
 
+/* Same layer step with the gate GEMMs on the bf16 matrix cores at fp32 accuracy: every
+ * fp32 operand is split exactly into three bf16 pieces (spmi_split_bf16x3 for the
+ * weights, in-kernel for x and the state) and each product is summed from the six piece
+ * products above 2^-24; pre-activations agree with an fp32 FMA chain to a few fp32
+ * roundings.  ws_ih / ws_hh: weight_ih [G*H, I] / weight_hh [G*H, H] (torch's own
+ * layout) passed through spmi_split_bf16x3, which writes [cols/16][3][rows][16] bfloat16
+ * (3 * rows * cols elements).  Other arguments as spmi_cell_fused_fwd, same shape limits. */
+int spmi_split_bf16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
+                      void* out /*device bf16, 3*rows*cols*/, void* stream);
+int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
+                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream);
+
 /* ------------------------------------------------------------------------
  * Attention encoder.  Replace what dgl GATConv.forward runs on the graph
  * (reference call sites: GAT in staticGraphEncoder.py:170,174,190):

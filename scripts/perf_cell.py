@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--h", type=int, default=128)
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "fp32"])
     a = ap.parse_args()
+    ops.CELL_GEMM = a.gemm
     dev = torch.device("cuda:0")
     x = torch.randn(a.n, a.i, device=dev)
     for kind, g in (("gru", 3), ("lstm", 4), ("rnn", 1)):

@@ -1,0 +1,486 @@
+// One recurrent layer step as ONE kernel for gfx950, fp32 results from the bf16 matrix
+// cores: every fp32 operand is split exactly into three bf16 pieces
+// (v = hi + mid + lo, 3 x 8 significand bits = the 24 of fp32) and a product x*w is summed
+// from the six piece products of weight above 2^-24 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+// mid*mid), each exact in the fp32 accumulator's input.  The dropped terms are below
+// 3 * 2^-24 |x||w|, the size of fp32's own rounding, so the gate pre-activations agree with
+// an fp32 FMA chain to a few units of fp32 rounding (measured against the CPU checker in the
+// tests), while six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x the matrix rate.
+//
+// Replaces the same reference lines as cell_fused.hip: torch.nn.GRU / LSTM / RNN as driven
+// by SequentialDecoder.forward / LSTM.forward (spiro/dtdg/models/decoder/torch/
+// sequentialDecoder/implicitTimeModels.py:144-158, :214-230) with NodeMemory.get_memory /
+// update_memory (:48-54).
+//
+// Mapping (as in cell_fused.hip): a workgroup owns 128 batch rows and all hidden units of
+// them; waves form a 4 x WC grid of 32-row groups x column groups, JSUB 32-unit column
+// blocks x NACC accumulator sets per wave.  K runs in steps of 16 through a double-buffered
+// LDS stage.  Weights arrive pre-split and pre-tiled ([K/16][3][G*H][16] bf16: the B image
+// of a K-step is one contiguous block); x and state rows are split while they are staged.
+// Both operand images are [piece][row or n][16 k] with 32-byte rows: a wave's
+// ds_read_b128 of a fragment covers 2 KB contiguously (conflict-free), one read per piece.
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kRows = 128;
+constexpr int kBK = 16;
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+
+enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_RNN = 2 };
+
+template <int CELL>
+struct Cell;
+template <>
+struct Cell<CELL_GRU> {
+  static constexpr int NG = 3, NACC = 4;
+  static constexpr int acc_x[3] = {0, 1, 2};
+  static constexpr int acc_h[3] = {0, 1, 3};
+};
+template <>
+struct Cell<CELL_LSTM> {
+  static constexpr int NG = 4, NACC = 4;
+  static constexpr int acc_x[4] = {0, 1, 2, 3};
+  static constexpr int acc_h[4] = {0, 1, 2, 3};
+};
+template <>
+struct Cell<CELL_RNN> {
+  static constexpr int NG = 1, NACC = 1;
+  static constexpr int acc_x[1] = {0};
+  static constexpr int acc_h[1] = {0};
+};
+
+struct SplitArgs {
+  const float* x;
+  int64_t ldx;
+  int I;
+  const __bf16* ws_ih;  // [I/16][3][NG*H][16]
+  const __bf16* ws_hh;  // [H/16][3][NG*H][16]
+  const float* b_ih;
+  const float* b_hh;
+  float* h_mem;
+  float* c_mem;
+  const int64_t* ids;
+  int64_t M;
+  int H;
+  float* h_out;
+  float* c_out;
+  int mem_write;
+  float* saved;
+  int ablate;  // timing experiments only: bit 0 no MFMA, 1 no loop loads, 2 no LDS stores, 3 no epilogue
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float tanhf_(float v) {
+  const float e = __expf(2.0f * fminf(v, 15.0f));
+  return (e - 1.0f) * __frcp_rn(e + 1.0f);
+}
+
+// v = hi + mid + lo exactly (each difference of an fp32 and its bf16 rounding is exact).
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = static_cast<__bf16>(v);
+  const float r1 = v - static_cast<float>(hi);
+  mid = static_cast<__bf16>(r1);
+  lo = static_cast<__bf16>(r1 - static_cast<float>(mid));
+}
+
+// Weights [rows][cols] fp32 -> [cols/16][3 pieces][rows][16] bf16: for one K-step the three
+// piece images of all rows are one contiguous block in the order the LDS stage wants them,
+// so the staging loads are fully coalesced.
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, int64_t rows, int64_t cols,
+                                    __bf16* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t n = i / cols, k = i % cols;
+  __bf16 hi, mid, lo;
+  split3(w[i], hi, mid, lo);
+  const int64_t base = (k / 16) * 3 * rows * 16 + n * 16 + (k % 16);
+  out[base] = hi;
+  out[base + rows * 16] = mid;
+  out[base + 2 * rows * 16] = lo;
+}
+
+template <int APT, int BPT>
+struct StageRegs {
+  float4 a[APT];
+  uint4 b[BPT];
+};
+
+// Global loads of one K-step into registers.  Addresses are "wave-uniform base + small
+// per-thread offset" wherever the rows are contiguous (x always; the state unless `ids`
+// redirects rows), which keeps the loop free of 64-bit per-thread pointers.
+template <int APT, int BPT, typename AOff>
+__device__ __forceinline__ void load_stage(StageRegs<APT, BPT>& r, const float* abase,
+                                           const AOff (&aoff)[APT], int k0, const __bf16* bbase,
+                                           const int (&boff)[BPT], int brow0) {
+#pragma unroll
+  for (int i = 0; i < APT; ++i) r.a[i] = *reinterpret_cast<const float4*>(abase + aoff[i] + k0);
+  const __bf16* b = bbase + static_cast<int64_t>(brow0) * 16;  // wave-uniform K-step base
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    // chunks past the tile read row 0 of the step (valid memory) and are not stored
+    r.b[i] = *reinterpret_cast<const uint4*>(b + boff[i]);
+  }
+}
+
+template <int APT, int BPT, int B16, int THREADS, int A_PLANE, int A_BYTES>
+__device__ __forceinline__ void store_stage(const StageRegs<APT, BPT>& r, char* stage,
+                                            const int (&a_dst)[APT], int tid) {
+#pragma unroll
+  for (int i = 0; i < APT; ++i) {
+    bf16x4 hi, mid, lo;
+    const float v[4] = {r.a[i].x, r.a[i].y, r.a[i].z, r.a[i].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __bf16 h1, m1, l1;
+      split3(v[q], h1, m1, l1);
+      hi[q] = h1;
+      mid[q] = m1;
+      lo[q] = l1;
+    }
+    *reinterpret_cast<bf16x4*>(stage + a_dst[i]) = hi;
+    *reinterpret_cast<bf16x4*>(stage + A_PLANE + a_dst[i]) = mid;
+    *reinterpret_cast<bf16x4*>(stage + 2 * A_PLANE + a_dst[i]) = lo;
+  }
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int c = tid + i * THREADS;
+    if ((i + 1) * THREADS <= B16 || c < B16)
+      *reinterpret_cast<uint4*>(stage + A_BYTES + c * 16) = r.b[i];
+  }
+}
+
+// The MFMAs of one K-step (16) of one wave: three A fragments, then per 32-column block
+// three B fragments and the six piece products, smallest terms first.  The next block's
+// fragments are read while the current block's MFMAs issue.
+template <int CELL, int JSUB, int JC, int A_PLANE, int B_PLANE, bool HPHASE>
+__device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC], const char* sa,
+                                           const char* sb) {
+  using C = Cell<CELL>;
+  constexpr int NB = C::NG * JSUB;
+  constexpr int ROWB = kBK * 2;
+  const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa);
+  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + A_PLANE);
+  const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(sa + 2 * A_PLANE);
+  // Two waves per SIMD (JSUB == 2): the next block's fragments are read while the current
+  // block's MFMAs issue.  Four waves per SIMD (JSUB == 1): the other waves cover the LDS
+  // latency and the registers of a second fragment set are not affordable.
+  constexpr bool PREFETCH = JSUB > 1;
+  bf16x8 b_cur[3], b_nxt[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b_cur[q] = *reinterpret_cast<const bf16x8*>(sb + q * B_PLANE);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (PREFETCH && i + 1 < NB) {
+      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * ROWB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b_nxt[q] = *reinterpret_cast<const bf16x8*>(sb + off + q * B_PLANE);
+    }
+    if (PREFETCH) __builtin_amdgcn_sched_barrier(0);
+    const int g = i / JSUB, sub = i % JSUB;
+    const int ai = HPHASE ? C::acc_h[g] : C::acc_x[g];
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b_cur[0], acc[sub][ai], 0, 0, 0);
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[2], acc[sub][ai], 0, 0, 0);
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[1], acc[sub][ai], 0, 0, 0);
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[0], acc[sub][ai], 0, 0, 0);
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[1], acc[sub][ai], 0, 0, 0);
+    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[0], acc[sub][ai], 0, 0, 0);
+    if (PREFETCH) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];
+    } else if (i + 1 < NB) {
+      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * ROWB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b_cur[q] = *reinterpret_cast<const bf16x8*>(sb + off + q * B_PLANE);
+    }
+  }
+}
+
+template <int CELL, int JSUB, int WC, bool IDS>
+__global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel(SplitArgs p) {
+  using C = Cell<CELL>;
+  constexpr int THREADS = 256 * WC;
+  constexpr int NG = C::NG, NACC = C::NACC;
+  constexpr int JW = JSUB * 32;               // hidden units per wave
+  constexpr int JC = JW * WC;                 // hidden units per pass
+  constexpr int NC = NG * JC;                 // B-tile rows (output columns)
+  constexpr int ROWB = kBK * 2;               // bytes of one image row (16 bf16)
+  constexpr int A_PLANE = kRows * ROWB;       // one piece of the A tile
+  constexpr int B_PLANE = NC * ROWB;
+  constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int APT = (kRows * kBK / 4) / THREADS;           // float4 of the A tile per thread
+  constexpr int B16 = B_BYTES / 16;                          // 16-byte chunks of the B tile
+  constexpr int BPT = (B16 + THREADS - 1) / THREADS;
+  static_assert((kRows * kBK / 4) % THREADS == 0, "A tile must divide over the threads");
+
+  extern __shared__ float4 smem4[];
+  char* smem = reinterpret_cast<char*>(smem4);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar registers
+  const int rg = wave & 3;
+  const int cg = wave >> 2;
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kRows;
+  const int H = p.H;
+  const int GH = NG * H;
+
+  // A staging: float4 number idx covers row idx / 4, k (idx % 4) * 4 .. +3
+  using HOff = typename std::conditional<IDS, int64_t, int>::type;
+  const float* xbase = p.x + row0 * p.ldx;
+  const float* hbase = IDS ? p.h_mem : p.h_mem + row0 * H;
+  int ax[APT];
+  HOff ah[APT];
+  int a_dst[APT];
+#pragma unroll
+  for (int i = 0; i < APT; ++i) {
+    const int idx = tid + i * THREADS;
+    const int c4 = (idx & 3) * 4;
+    int trow = idx >> 2;
+    a_dst[i] = trow * ROWB + c4 * 2;
+    if (row0 + trow >= p.M) trow = static_cast<int>(p.M - 1 - row0);  // clamp: computed, not stored
+    ax[i] = trow * static_cast<int>(p.ldx) + c4;
+    if constexpr (IDS) ah[i] = p.ids[row0 + trow] * H + c4;
+    else ah[i] = trow * H + c4;
+  }
+
+  const int a_rd = (rg * 32 + lr) * ROWB + lh * 16;
+  const int b_rd = A_BYTES + (cg * JW + lr) * ROWB + lh * 16;
+
+  for (int j0 = 0; j0 < H; j0 += JC) {
+    // B staging: chunk c -> piece c / (2 NC), tile row (c % (2 NC)) / 2, half (c & 1).  The
+    // weights are stored [K/16][piece][n][16], so a K-step advances every offset by 3*GH*16.
+    int boff[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int c = tid + i * THREADS;
+      const int piece = c / (2 * NC);
+      const int nl = (c % (2 * NC)) >> 1;
+      const int brow = (c < B16) ? piece * GH + (nl / JC) * H + j0 + (nl % JC) : 0;
+      boff[i] = brow * 16 + (c & 1) * 8;
+    }
+    const int bstep = 3 * GH;  // 16-element rows per K-step
+
+    f32x16 acc[JSUB][NACC];
+#pragma unroll
+    for (int s = 0; s < JSUB; ++s)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][a][e] = 0.0f;
+
+    StageRegs<APT, BPT> regs;
+
+    const int tiles_x = p.I / kBK;
+    const int tiles_h = H / kBK;
+    __syncthreads();  // the previous pass has finished reading both buffers
+    load_stage<APT, BPT>(regs, xbase, ax, 0, p.ws_ih, boff, 0);
+    store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < tiles_x; ++t) {
+      if (!(p.ablate & 2)) {
+      if (t + 1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, (t + 1) * kBK, p.ws_ih, boff, (t + 1) * bstep);
+      else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
+      }
+      if (!(p.ablate & 1))
+      mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, false>(acc, smem + buf * STAGE + a_rd,
+                                                          smem + buf * STAGE + b_rd);
+      if (!(p.ablate & 4))
+      store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
+      __syncthreads();
+      buf ^= 1;
+    }
+    for (int t = 0; t < tiles_h; ++t) {
+      const bool more = t + 1 < tiles_h;
+      if (more && !(p.ablate & 2)) load_stage<APT, BPT>(regs, hbase, ah, (t + 1) * kBK, p.ws_hh, boff, (t + 1) * bstep);
+      if (!(p.ablate & 1))
+      mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, true>(acc, smem + buf * STAGE + a_rd,
+                                                         smem + buf * STAGE + b_rd);
+      if (more && !(p.ablate & 4))
+        store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    // ---- epilogue: gates, state update, stores (same accumulator layout as the fp32 kernel).
+    // Row addresses are "uniform row base + lane offset", so that no per-element 64-bit
+    // address is kept alive across the K loop.
+#pragma unroll
+    for (int s = 0; s < JSUB; ++s) {
+      const int j = j0 + cg * JW + s * 32 + lr;
+      float bi[NG], bhh[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        bi[g] = p.b_ih ? p.b_ih[g * H + j] : 0.0f;
+        bhh[g] = p.b_hh ? p.b_hh[g * H + j] : 0.0f;
+      }
+      const int voff = 4 * lh * H + j;  // lane part of every address below
+      const int64_t urow0 = row0 + rg * 32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t urow = urow0 + ((e & 3) + 8 * (e >> 2));  // uniform part of the row
+        const int64_t row = urow + 4 * lh;
+        if (row >= p.M || (p.ablate & 8)) continue;
+        float* ho = p.h_out + urow * H;
+        float* hm;
+        float* cm = nullptr;
+        if constexpr (IDS) {
+          const int64_t mr = p.ids[row] * H + j;
+          hm = p.h_mem + mr - voff;
+          if constexpr (CELL == CELL_LSTM) cm = p.c_mem + mr - voff;
+        } else {
+          hm = p.h_mem + urow * H;
+          if constexpr (CELL == CELL_LSTM) cm = p.c_mem + urow * H;
+        }
+        if constexpr (CELL == CELL_GRU) {
+          const float h = hm[voff];
+          const float r = sigmoidf_(acc[s][0][e] + (bi[0] + bhh[0]));
+          const float z = sigmoidf_(acc[s][1][e] + (bi[1] + bhh[1]));
+          const float hn = acc[s][3][e] + bhh[2];
+          const float n = tanhf_(acc[s][2][e] + bi[2] + r * hn);
+          const float hy = n + z * (h - n);
+          ho[voff] = hy;
+          if (p.saved) {
+            float* sv = p.saved + urow * 5 * H + (4 * lh * 5 * H + j);
+            sv[0] = r; sv[H] = z; sv[2 * H] = n; sv[3 * H] = hn; sv[4 * H] = h;
+          }
+          if (p.mem_write && JC == H) hm[voff] = hy;
+        } else if constexpr (CELL == CELL_LSTM) {
+          const float c = cm[voff];
+          const float ig = sigmoidf_(acc[s][0][e] + (bi[0] + bhh[0]));
+          const float fg = sigmoidf_(acc[s][1][e] + (bi[1] + bhh[1]));
+          const float gg = tanhf_(acc[s][2][e] + (bi[2] + bhh[2]));
+          const float og = sigmoidf_(acc[s][3][e] + (bi[3] + bhh[3]));
+          const float cy = fg * c + ig * gg;
+          const float tc = tanhf_(cy);
+          const float hy = og * tc;
+          ho[voff] = hy;
+          (p.c_out + urow * H)[voff] = cy;
+          if (p.saved) {
+            float* sv = p.saved + urow * 6 * H + (4 * lh * 6 * H + j);
+            sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c; sv[5 * H] = tc;
+          }
+          if (p.mem_write && JC == H) {
+            hm[voff] = hy;
+            cm[voff] = cy;
+          }
+        } else {
+          const float hy = tanhf_(acc[s][0][e] + (bi[0] + bhh[0]));
+          ho[voff] = hy;
+          if (p.mem_write && JC == H) hm[voff] = hy;
+        }
+      }
+    }
+  }
+
+  // With several column passes the state rows stay readable until the last pass is done.
+  if (p.mem_write && JC != H) {
+    __syncthreads();
+    const int per_row = H / 4;
+    for (int idx = tid; idx < kRows * per_row; idx += THREADS) {
+      const int64_t row = row0 + idx / per_row;
+      if (row >= p.M) break;
+      const int c4 = (idx % per_row) * 4;
+      const int64_t mrow = (p.ids ? p.ids[row] : row) * H + c4;
+      *reinterpret_cast<float4*>(p.h_mem + mrow) =
+          *reinterpret_cast<const float4*>(p.h_out + row * H + c4);
+      if constexpr (CELL == CELL_LSTM)
+        *reinterpret_cast<float4*>(p.c_mem + mrow) =
+            *reinterpret_cast<const float4*>(p.c_out + row * H + c4);
+    }
+  }
+}
+
+template <int CELL, int JSUB, int WC>
+int launch_config(const SplitArgs& a, hipStream_t st) {
+  constexpr int NC = Cell<CELL>::NG * JSUB * 32 * WC;
+  constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2);
+  static_assert(lds <= 160 * 1024, "LDS stage does not fit");
+  auto plain = split_cell_kernel<CELL, JSUB, WC, false>;
+  auto gathered = split_cell_kernel<CELL, JSUB, WC, true>;
+  static bool configured = false;
+  if (!configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plain),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gathered),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const unsigned grid = static_cast<unsigned>((a.M + kRows - 1) / kRows);
+  if (a.ids) gathered<<<grid, 256 * WC, lds, st>>>(a);
+  else plain<<<grid, 256 * WC, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("split_cell");
+  return SPMI_OK;
+}
+
+template <int CELL>
+int launch_split(const SplitArgs& a, hipStream_t st) {
+  if (a.H % 128 == 0) return launch_config<CELL, 2, 2>(a, st);
+  if (a.H % 64 == 0) return launch_config<CELL, 1, 2>(a, st);
+  return launch_config<CELL, 1, 1>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmi_split_bf16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
+  SPMI_REQUIRE(rows >= 1 && cols >= 16 && cols % 16 == 0 && w && out, SPMI_ERR_INVALID_ARG,
+               "spmi_split_bf16x3: needs rows >= 1, cols a multiple of 16 and non-null pointers");
+  const int64_t n = rows * cols;
+  split_bf16x3_kernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(
+      w, rows, cols, static_cast<__bf16*>(out));
+  SPMI_CHECK_LAUNCH("split_bf16x3");
+  return SPMI_OK;
+}
+
+int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
+                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream) {
+  SPMI_REQUIRE(cell >= CELL_GRU && cell <= CELL_RNN, SPMI_ERR_INVALID_ARG,
+               "spmi_cell_split_fwd: bad cell code %d", cell);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
+               "spmi_cell_split_fwd: bad M=%lld", (long long)M);
+  SPMI_REQUIRE(I >= 32 && I % 32 == 0 && H >= 32 && H % 32 == 0 && I <= 8192 && H <= 8192,
+               SPMI_ERR_UNSUPPORTED,
+               "spmi_cell_split_fwd: needs I %% 32 == 0 and H %% 32 == 0 (I=%lld H=%lld)",
+               (long long)I, (long long)H);
+  SPMI_REQUIRE(ldx < (int64_t{1} << 20), SPMI_ERR_UNSUPPORTED,
+               "spmi_cell_split_fwd: leading dimension %lld too large", (long long)ldx);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(x && ws_ih && ws_hh && h_mem && h_out && ldx >= I && ldx % 4 == 0,
+               SPMI_ERR_INVALID_ARG, "spmi_cell_split_fwd: null pointer or bad ldx");
+  SPMI_REQUIRE(cell != CELL_LSTM || (c_mem && c_out), SPMI_ERR_INVALID_ARG,
+               "spmi_cell_split_fwd: LSTM needs c_mem and c_out");
+  for (const void* q : {(const void*)x, ws_ih, ws_hh, (const void*)h_mem, (const void*)h_out,
+                        (const void*)c_mem, (const void*)c_out})
+    SPMI_REQUIRE(!q || (reinterpret_cast<uintptr_t>(q) & 15u) == 0, SPMI_ERR_INVALID_ARG,
+                 "spmi_cell_split_fwd: pointers must be 16-byte aligned");
+  SplitArgs a{};
+  a.x = x; a.ldx = ldx; a.I = static_cast<int>(I);
+  a.ws_ih = static_cast<const __bf16*>(ws_ih); a.ws_hh = static_cast<const __bf16*>(ws_hh);
+  a.b_ih = b_ih; a.b_hh = b_hh;
+  a.h_mem = h_mem; a.c_mem = c_mem; a.ids = ids; a.M = M; a.H = static_cast<int>(H);
+  a.h_out = h_out; a.c_out = c_out; a.mem_write = mem_write; a.saved = saved;
+  { const char* e = getenv("SPMI_SPLIT_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+  hipStream_t st = spmi::as_stream(stream);
+  if (cell == CELL_GRU) return launch_split<CELL_GRU>(a, st);
+  if (cell == CELL_LSTM) return launch_split<CELL_LSTM>(a, st);
+  return launch_split<CELL_RNN>(a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""The one-kernel recurrent layer step in both of its arithmetic modes, against the CPU
+oracle: "fp32" (v_mfma_f32_32x32x2_f32) and "bf16x3" (fp32 operands split exactly into
+three bf16 pieces, six piece products per term on the bf16 matrix cores).  Both must meet
+the same fp32 bar (1e-5 absolute on gate outputs, which are bounded by 1)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from spiral_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["bf16x3", "fp32"])
+def mode(request):
+    old = ops.CELL_GEMM
+    ops.CELL_GEMM = request.param
+    yield request.param
+    ops.CELL_GEMM = old
+
+
+def _params(g, i, h, dev, seed):
+    gen = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=gen) * 0.1)  # about the scale of torch's uniform(-1/sqrt(H), 1/sqrt(H))
+    return [t.to(dev) for t in (mk(g * h, i), mk(g * h, h), mk(g * h), mk(g * h))]
+
+
+@pytest.mark.parametrize("m,i,h,gather", [(1000, 128, 128, False), (777, 64, 32, True), (130, 32, 96, False),
+                                          (4097, 160, 64, True), (129, 256, 256, False)])
+def test_gru_lstm_rnn_steps(dev, mode, m, i, h, gather):
+    cpu = lambda t: t.detach().cpu().numpy()
+    n_mem = m + 50 if gather else m
+    gen = torch.Generator().manual_seed(m + i + h)
+    x = (torch.randn(m, i, generator=gen) * 1.5).to(dev)
+    ids = torch.randperm(n_mem, generator=gen)[:m].to(dev) if gather else None
+    sel = cpu(ids) if gather else np.arange(m)
+    for kind, g in (("gru", 3), ("lstm", 4), ("rnn", 1)):
+        w_ih, w_hh, b_ih, b_hh = _params(g, i, h, dev, seed=g)
+        mem_h = torch.randn(n_mem, h, generator=gen).to(dev)
+        mem_c = torch.randn(n_mem, h, generator=gen).to(dev)
+        h0, c0 = cpu(mem_h).copy(), cpu(mem_c).copy()
+        with torch.no_grad():
+            if kind == "gru":
+                out = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem_h, ids)
+                want = orc.gru_cell(cpu(x), h0[sel], cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
+            elif kind == "lstm":
+                out = ops.lstm_cell(x, w_ih, w_hh, b_ih, b_hh, mem_h, mem_c, ids)
+                out = out[0] if isinstance(out, tuple) else out
+                want, want_c = orc.lstm_cell(cpu(x), h0[sel], c0[sel], cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
+                assert np.abs(cpu(mem_c)[sel] - want_c).max() < 2e-5
+            else:
+                out = ops.rnn_cell(x, w_ih, w_hh, b_ih, b_hh, mem_h, ids)
+                want = orc.rnn_cell(cpu(x), h0[sel], cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
+        assert np.abs(cpu(out) - want).max() < 1e-5, (kind, mode)
+        after = cpu(mem_h)
+        assert np.array_equal(after[sel], cpu(out))                 # rows written back in place
+        untouched = np.setdiff1d(np.arange(n_mem), sel)
+        assert np.array_equal(after[untouched], h0[untouched])      # and only those rows
+
+
+def test_split_pieces_are_exact(dev):
+    w = torch.randn(96, 64, device=dev) * torch.logspace(-6, 3, 64, device=dev)
+    pieces = ops.split_bf16x3(w)                                    # [cols/16, 3, rows, 16]
+    assert pieces.shape == (4, 3, 96, 16) and pieces.dtype == torch.bfloat16
+    total = pieces.float().sum(1)                                   # [4, 96, 16]
+    back = total.permute(1, 0, 2).reshape(96, 64)
+    assert torch.equal(back, w)
