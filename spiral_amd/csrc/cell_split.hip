@@ -21,7 +21,6 @@
 // Both operand images are [piece][row or n][16 k] with 32-byte rows: a wave's
 // ds_read_b128 of a fragment covers 2 KB contiguously (conflict-free), one read per piece.
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -75,7 +74,6 @@ struct SplitArgs {
   float* c_out;
   int mem_write;
   float* saved;
-  int ablate;  // timing experiments only: bit 0 no MFMA, 1 no loop loads, 2 no LDS stores, 3 no epilogue
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
@@ -291,25 +289,20 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
     __syncthreads();
     int buf = 0;
     for (int t = 0; t < tiles_x; ++t) {
-      if (!(p.ablate & 2)) {
       if (t + 1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, (t + 1) * kBK, p.ws_ih, boff, (t + 1) * bstep);
       else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
-      }
-      if (!(p.ablate & 1))
       mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, false>(acc, smem + buf * STAGE + a_rd,
                                                           smem + buf * STAGE + b_rd);
-      if (!(p.ablate & 4))
       store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
       __syncthreads();
       buf ^= 1;
     }
     for (int t = 0; t < tiles_h; ++t) {
       const bool more = t + 1 < tiles_h;
-      if (more && !(p.ablate & 2)) load_stage<APT, BPT>(regs, hbase, ah, (t + 1) * kBK, p.ws_hh, boff, (t + 1) * bstep);
-      if (!(p.ablate & 1))
+      if (more) load_stage<APT, BPT>(regs, hbase, ah, (t + 1) * kBK, p.ws_hh, boff, (t + 1) * bstep);
       mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, true>(acc, smem + buf * STAGE + a_rd,
                                                          smem + buf * STAGE + b_rd);
-      if (more && !(p.ablate & 4))
+      if (more)
         store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
       __syncthreads();
       buf ^= 1;
@@ -333,7 +326,7 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
       for (int e = 0; e < 16; ++e) {
         const int64_t urow = urow0 + ((e & 3) + 8 * (e >> 2));  // uniform part of the row
         const int64_t row = urow + 4 * lh;
-        if (row >= p.M || (p.ablate & 8)) continue;
+        if (row >= p.M) continue;
         float* ho = p.h_out + urow * H;
         float* hm;
         float* cm = nullptr;
@@ -476,7 +469,6 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
   a.b_ih = b_ih; a.b_hh = b_hh;
   a.h_mem = h_mem; a.c_mem = c_mem; a.ids = ids; a.M = M; a.H = static_cast<int>(H);
   a.h_out = h_out; a.c_out = c_out; a.mem_write = mem_write; a.saved = saved;
-  { const char* e = getenv("SPMI_SPLIT_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   hipStream_t st = spmi::as_stream(stream);
   if (cell == CELL_GRU) return launch_split<CELL_GRU>(a, st);
   if (cell == CELL_LSTM) return launch_split<CELL_LSTM>(a, st);
