@@ -203,6 +203,15 @@ def main():
                          "recurrent update of snapshot t-1; 'plain' gathers in front of both layers")
     ap.add_argument("--gather-dtype", default="f32", choices=["f32", "bf16"],
                     help="N>1: payload of the all-gather (bf16 halves the bytes; sums stay f32)")
+    ap.add_argument("--no-gc-freeze", action="store_true",
+                    help="leave Python's garbage collector as it is.  By default the bench runs "
+                         "gc.collect() + gc.freeze() after warm-up: a full collection of the set-up's "
+                         "objects costs 35-40 ms with torch loaded and otherwise lands in the timed "
+                         "region of some runs and not of others")
+    ap.add_argument("--per-step", action="store_true",
+                    help="also print the per-step stage times (ms) of the timed region, to stderr")
+    ap.add_argument("--no-fused-head", action="store_true",
+                    help="run the MLP head layer by layer in torch instead of the one-kernel inference head")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="train: forward + MSE loss + backward + Adam step per snapshot "
                          "(the loop of examples/torch/citation_prediction.py:90-101)")
@@ -227,6 +236,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    MLP.FUSE_EVAL = not args.no_fused_head
     w = WORKLOADS[args.workload]
     n_total, e_total, f = w["n"] * world, w["e"] * world, w["f"]
     n_snap = min(args.snapshots or w["snapshots"], max(args.steps, 1))
@@ -417,6 +427,21 @@ def main():
     for i in range(args.warmup):
         run(i, False)
     drain()  # the timed region starts with an empty pipeline ...
+    import gc
+    if not args.no_gc_freeze:
+        gc.collect()
+        gc.freeze()
+    if args.per_step and rank == 0:
+        gc_t0 = {}
+
+        def _gc_log(phase, info):
+            if phase == "start":
+                gc_t0["t"] = time.perf_counter()
+            else:
+                print(f"gc: generation={info['generation']} collected={info['collected']} "
+                      f"ms={(time.perf_counter() - gc_t0.get('t', time.perf_counter())) * 1e3:.2f} "
+                      f"at_timed_step~{len(stage_events)}", file=sys.stderr, flush=True)
+        gc.callbacks.append(_gc_log)
     launch_log = []
     G.set_launch_log(launch_log)
     barrier()
@@ -450,6 +475,17 @@ def main():
     for i, name in enumerate(stage_names):
         stages[name + "_ms"] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_events) / max(len(stage_events), 1)
 
+    if rank == 0 and args.per_step:
+        st = torch.cuda.memory_stats(dev)
+        print("allocator: " + " ".join(f"{k}={st.get(k, 0)}" for k in (
+            "num_alloc_retries", "num_device_alloc", "num_device_free", "num_ooms",
+            "reserved_bytes.all.peak", "allocated_bytes.all.peak")), file=sys.stderr, flush=True)
+    if rank == 0 and args.per_step and stage_events:
+        for i, ev in enumerate(stage_events):
+            series = [round(ev[j].elapsed_time(ev[j + 1]), 3) for j in range(len(stage_names))]
+            gap = round(stage_events[i - 1][len(stage_names)].elapsed_time(ev[0]), 3) if i else 0.0
+            print(f"step {i:3d} gap_before={gap:8.3f} " + " ".join(f"{n}={v:7.3f}" for n, v in zip(stage_names, series)),
+                  file=sys.stderr, flush=True)
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         result = {
@@ -468,6 +504,9 @@ def main():
                                 f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu), "
                                 f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
+                       "head": "one-kernel inference MLP" if MLP.FUSE_EVAL and not train else "torch layers",
+                       "host": ("python gc left running" if args.no_gc_freeze
+                                else "gc.collect() + gc.freeze() after warm-up, before the timed region"),
                        "gate_gemm": ("fp32 results from bf16 matrix cores: operands split exactly in three "
                                      "bf16 pieces, six piece products per term"
                                      if ops.CELL_GEMM == "bf16x3" else "fp32 matrix instruction"),

@@ -314,6 +314,28 @@ int spmi_gemm_tn(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/
                  int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Output head in inference, one kernel: the MLP of
+ * spiro/dtdg/models/decoder/torch/simpleDecoder.py:45-79 ([Linear,
+ * BatchNorm1d, ReLU, Dropout] x k + Linear) as called from
+ * SequentialDecoder.forward (implicitTimeModels.py:157-158), in eval mode:
+ * BatchNorm is folded into the preceding Linear by the caller, Dropout is the
+ * identity.  x [M, I] is read once, out [M, width of the last layer] written.
+ *   layer 1: w1t = weight transposed and zero-padded to [I][P], P = 8 / 16 / 32
+ *            (the smallest that holds out1), b1 [P];
+ *   layers 2..: rest_packed = per layer the weight in torch's [out, in]
+ *            layout followed by its bias [out] (zeros if none), back to back,
+ *            device memory; rest_out / rest_relu are HOST arrays of n_rest ints;
+ *   relu flags per layer; final_act: 0 none, 1 sigmoid, 2 relu, 3 tanh.
+ * Limits (spmi_mlp_head_supported): I a multiple of 32, widths <= 32,
+ * I * P <= 8192, at most 7 layers after the first.
+ * ---------------------------------------------------------------------- */
+int spmi_mlp_head_supported(int64_t I, int32_t out1, int32_t n_rest, const int32_t* rest_out);
+int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const float* w1t,
+                      const float* b1, int32_t out1, int32_t relu1, int32_t n_rest,
+                      const float* rest_packed, const int32_t* rest_out, const int32_t* rest_relu,
+                      int32_t final_act, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,80 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return _Linear.apply(x, weight, bias)
 
 
+# --------------------------------------------------------------------------- output head
+_FINAL_ACT = {None: 0, "none": 0, "sigmoid": 1, "relu": 2, "tanh": 3}
+
+
+def _int_array(values):
+    import ctypes
+
+    return (ctypes.c_int32 * max(len(values), 1))(*values)
+
+
+def mlp_head_supported(in_width: int, widths) -> bool:
+    """Whether the one-kernel head covers these layer widths (input a multiple of 32, every
+    layer at most 32 wide, weights small enough for LDS)."""
+    import ctypes
+
+    if not widths:
+        return False
+    rest = _int_array(list(widths[1:]))
+    return bool(nv.lib().spmi_mlp_head_supported(in_width, widths[0], len(widths) - 1,
+                                                 ctypes.cast(rest, ctypes.c_void_p)))
+
+
+def mlp_head(x: torch.Tensor, layers=None, final_act: Optional[str] = None, packed=None
+             ) -> torch.Tensor:
+    """Inference pass of a small MLP over the rows of x in one launch.  `layers`: list of
+    (weight [out, in], bias [out] or None, relu: bool) with BatchNorm already folded in;
+    or `packed` = pack_mlp_head(layers, device), which callers with fixed weights keep, so
+    that a call queues nothing but the kernel."""
+    nv.require_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise nv.SpmiError("mlp_head expects a 2-D float32 matrix")
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if packed is None:
+        packed = pack_mlp_head(layers, x.device)
+    w1t, b1p, out1, relu1, rest, outs, relus, n_rest, width = packed[:9]
+    out = torch.empty(x.shape[0], width, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().spmi_mlp_head_fwd(
+            nv.ptr(x), x.stride(0), x.shape[0], w1t.shape[0], nv.ptr(w1t), nv.ptr(b1p), out1, relu1,
+            n_rest, nv.ptr(rest), outs, relus, _FINAL_ACT[final_act], nv.ptr(out), width,
+            nv.stream()), "spmi_mlp_head_fwd")
+    return out
+
+
+def pack_mlp_head(layers, device):
+    """Device buffers in the layout spmi_mlp_head_fwd takes (see include/spmi.h)."""
+    w1, b1, relu1 = layers[0]
+    out1, in1 = w1.shape
+    o1p = 8 if out1 <= 8 else (16 if out1 <= 16 else 32)
+    w1t = torch.zeros(in1, o1p, dtype=torch.float32, device=device)
+    w1t[:, :out1] = w1.detach().t()
+    b1p = torch.zeros(o1p, dtype=torch.float32, device=device)
+    if b1 is not None:
+        b1p[:out1] = b1.detach()
+    pieces, rest_out, rest_relu = [], [], []
+    for w, b, relu in layers[1:]:
+        pieces.append(w.detach().reshape(-1).float())
+        pieces.append(torch.zeros(w.shape[0], device=device) if b is None else b.detach().float())
+        rest_out.append(w.shape[0])
+        rest_relu.append(int(relu))
+    import ctypes
+
+    rest = torch.cat(pieces) if pieces else None
+    width = rest_out[-1] if rest_out else out1
+    outs = ctypes.cast(_int_array(rest_out), ctypes.c_void_p)
+    relus = ctypes.cast(_int_array(rest_relu), ctypes.c_void_p)
+    # the ctypes arrays must outlive the casts: keep them on the tuple's tail
+    keep = (_int_array(rest_out), _int_array(rest_relu))
+    outs = ctypes.cast(keep[0], ctypes.c_void_p)
+    relus = ctypes.cast(keep[1], ctypes.c_void_p)
+    return (w1t, b1p, out1, int(relu1), rest, outs, relus, len(rest_out), width) + (keep,)
+
+
 # --------------------------------------------------------------------------- attention
 def _heavy(csr):
     return nv.ptr(csr.heavy_rows), csr.n_heavy, csr.heavy_thresh
