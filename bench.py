@@ -424,6 +424,25 @@ def main():
             while in_flight:
                 back(None)
 
+    # The pipelined exchange has only ever run on rehearsal ranks sharing one GPU.  Probe it
+    # once before warm-up; if any rank raises, every rank falls back to the plain exchange
+    # (all-gather in front of both layers) and the JSON line says so.
+    exchange_note = None
+    if pipelined:
+        failed = torch.zeros(1, device=dev)
+        try:
+            run(0, False)
+            drain()
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001 - reported, then the plain path takes over
+            failed.fill_(1)
+            in_flight.clear()
+            print(f"[rank {rank}] pipelined exchange failed, falling back: {exc!r}", file=sys.stderr, flush=True)
+        dist.all_reduce(failed)
+        if failed.item() > 0:
+            pipelined = False
+            exchange_note = "plain (pipelined exchange raised on at least one rank)"
+
     for i in range(args.warmup):
         run(i, False)
     drain()  # the timed region starts with an empty pipeline ...
@@ -510,6 +529,8 @@ def main():
                        "gate_gemm": ("fp32 results from bf16 matrix cores: operands split exactly in three "
                                      "bf16 pieces, six piece products per term"
                                      if ops.CELL_GEMM == "bf16x3" else "fp32 matrix instruction"),
+                       "exchange": exchange_note or (args.exchange if world > 1 and not train else
+                                                     ("plain" if world > 1 else None)),
                        "parallelism": (f"dst-row blocks x{world}, all-gather per layer" +
                                        (", layer-1 input replicated, layer-2 gather overlapped with the "
                                         "previous snapshot's recurrent update" if pipelined else "") +
