@@ -87,3 +87,66 @@ def test_snapshot_graph_surface():
     assert g2.num_edges() == 8 and g2.ndata["h"].shape == (5, 2)
     sn = Snapshot(g, 1)
     assert sn.to("cpu") is sn and sn.num_nodes() == 5
+
+
+# ---- output head: BatchNorm folding and the packed layout (host logic, no GPU) ------------
+def _mlp_with_stats(dims, out, act, seed):
+    import torch
+    from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP
+
+    torch.manual_seed(seed)
+    mlp = MLP(32, dims, output_dim=out, activation=act).eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen))
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.weight.copy_(torch.randn(m.num_features, generator=gen))
+                m.bias.copy_(torch.randn(m.num_features, generator=gen))
+    return mlp
+
+
+def test_folded_head_layers_equal_the_module_in_eval_mode():
+    import torch
+
+    for dims, out, act in (([10, 20, 10, 5], 1, "linear"), ([7], 3, "sigmoid"), ([], 4, "tanh"), ([8, 8], 2, "relu")):
+        mlp = _mlp_with_stats(dims, out, act, seed=len(dims))
+        x = torch.randn(50, 32)
+        layers = mlp._folded_layers()
+        assert len(layers) == len(dims) + 1
+        h = x
+        for w, b, relu in layers:
+            h = h @ w.t() + (0 if b is None else b)
+            if relu:
+                h = torch.relu(h)
+        fin = {None: lambda t: t, "sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}[mlp._final_act]
+        with torch.no_grad():
+            want = mlp.mlp(x)
+        assert torch.allclose(fin(h), want, rtol=1e-5, atol=1e-6)
+        assert [r for _, _, r in layers] == [True] * len(dims) + [False]
+        # cached until a parameter or a running statistic changes in place
+        assert mlp._folded_layers() is layers
+        with torch.no_grad():
+            mlp.layers[0].weight.add_(1.0)
+        assert mlp._folded_layers() is not layers
+
+
+def test_packed_head_layout():
+    import torch
+    from spiral_amd import ops
+
+    mlp = _mlp_with_stats([10, 20], 3, "linear", seed=5)
+    layers = mlp._folded_layers()
+    w1t, b1p, out1, relu1, rest, outs, relus, n_rest, width = ops.pack_mlp_head(layers, "cpu")[:9]
+    assert (out1, relu1, n_rest, width) == (10, 1, 2, 3)
+    assert w1t.shape == (32, 16) and b1p.shape == (16,)            # 10 outputs padded to 16
+    assert torch.equal(w1t[:, :10], layers[0][0].t()) and not w1t[:, 10:].any()
+    assert torch.equal(b1p[:10], layers[0][1]) and not b1p[10:].any()
+    w2, b2, _ = layers[1]
+    w3, b3, _ = layers[2]
+    assert torch.equal(rest, torch.cat([w2.reshape(-1), b2, w3.reshape(-1), b3]))
+    assert ops.mlp_head_supported(128, [10, 20, 10, 5, 1])
+    assert not ops.mlp_head_supported(128, [64, 1])                 # wider than the kernel holds
+    assert not ops.mlp_head_supported(100, [10, 1])                 # input not a multiple of 32
+    assert not ops.mlp_head_supported(1024, [32, 1])                # layer-1 weight beyond LDS budget
