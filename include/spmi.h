@@ -118,6 +118,10 @@ int spmi_csr_prefix_degree(const int32_t* indptr_all, const int32_t* eid_all, in
  * ---------------------------------------------------------------------- */
 int spmi_norm_from_indptr(const int32_t* indptr /*device [N+1]*/, int64_t N, int mode,
                           float* norm /*device [N]*/, void* stream);
+/* Same normaliser from an int64 degree vector (the output of spmi_degree or
+ * spmi_csr_prefix_degree), for the side of GraphConv whose CSR is not built. */
+int spmi_norm_from_degree(const int64_t* deg /*device [N]*/, int64_t N, int mode,
+                          float* norm /*device [N]*/, void* stream);
 
 /* ------------------------------------------------------------------------
  * Load-balance plan for the aggregation: rows whose degree exceeds

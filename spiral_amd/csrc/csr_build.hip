@@ -297,6 +297,15 @@ __global__ void norm_kernel(const int32_t* __restrict__ indptr, int64_t N, int m
   }
 }
 
+__global__ void norm_from_degree_kernel(const int64_t* __restrict__ deg, int64_t N, int mode,
+                                        float* __restrict__ norm) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < N) {
+    float d = fmaxf(static_cast<float>(deg[i]), 1.0f);
+    norm[i] = (mode == SPMI_NORM_RSQRT) ? (1.0f / sqrtf(d)) : (1.0f / d);
+  }
+}
+
 // ---- aggregation plan ---------------------------------------------------------------
 __global__ void plan_collect_kernel(const int32_t* __restrict__ indptr, int64_t N,
                                     int32_t heavy_thresh, int32_t* __restrict__ heavy_rows,
@@ -520,6 +529,19 @@ int spmi_norm_from_indptr(const int32_t* indptr, int64_t N, int mode, float* nor
   if (N == 0) return SPMI_OK;
   norm_kernel<<<(int)((N + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(indptr, N, mode, norm);
   SPMI_CHECK_LAUNCH("norm");
+  return SPMI_OK;
+}
+
+int spmi_norm_from_degree(const int64_t* deg, int64_t N, int mode, float* norm, void* stream) {
+  SPMI_REQUIRE(deg && norm, SPMI_ERR_INVALID_ARG, "spmi_norm_from_degree: null pointer");
+  SPMI_REQUIRE(N >= 0 && N < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
+               "spmi_norm_from_degree: bad N=%lld", (long long)N);
+  SPMI_REQUIRE(mode == SPMI_NORM_RSQRT || mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
+               "spmi_norm_from_degree: bad mode %d", mode);
+  if (N == 0) return SPMI_OK;
+  norm_from_degree_kernel<<<(int)((N + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(deg, N, mode,
+                                                                                      norm);
+  SPMI_CHECK_LAUNCH("norm_from_degree");
   return SPMI_OK;
 }
 

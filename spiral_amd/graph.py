@@ -16,7 +16,6 @@ and raises when asked to compute.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -44,23 +43,45 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.int64 else t.to(torch.int64)
 
 
-@dataclass
 class CSR:
-    """One grouping of a snapshot's edges on the device (int32, see include/spmi.h)."""
+    """One grouping of a snapshot's edges on the device (int32, see include/spmi.h).
 
-    indptr: torch.Tensor
-    indices: torch.Tensor
-    eid: Optional[torch.Tensor]  # original edge positions; None unless asked for
-    n_rows: int
-    n_cols: int
-    nnz: int
-    heavy_rows: Optional[torch.Tensor] = None
-    heavy_chunk_ptr: Optional[torch.Tensor] = None
-    n_heavy: int = 0
-    n_chunks: int = 0
-    heavy_thresh: int = HEAVY_THRESH
-    chunk: int = HEAVY_CHUNK
-    _partial: Dict[int, torch.Tensor] = field(default_factory=dict)
+    The status word of the build and the two sizes of the hub-row plan come back from the
+    device through a pinned buffer.  A CSR made with `defer=True` does not wait for them:
+    `ready()` (called by `n_heavy` / `n_chunks`, hence by every aggregation) does, and raises
+    there if the edge list held an id out of range.  Until then the host keeps queueing work
+    behind the build instead of idling on it."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, eid: Optional[torch.Tensor],
+                 n_rows: int, n_cols: int, nnz: int, heavy_rows: Optional[torch.Tensor] = None,
+                 heavy_chunk_ptr: Optional[torch.Tensor] = None, n_heavy: int = 0, n_chunks: int = 0,
+                 heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK, pending=None):
+        self.indptr, self.indices, self.eid = indptr, indices, eid  # eid: None unless asked for
+        self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
+        self.heavy_rows, self.heavy_chunk_ptr = heavy_rows, heavy_chunk_ptr
+        self._n_heavy, self._n_chunks = n_heavy, n_chunks
+        self.heavy_thresh, self.chunk = heavy_thresh, chunk
+        self._pending = pending  # (pinned int32[3], event, device int32[3]) until ready()
+        self._partial: Dict[int, torch.Tensor] = {}
+
+    def ready(self) -> "CSR":
+        if self._pending is not None:
+            host, event, _ = self._pending
+            event.synchronize()
+            status, self._n_heavy, self._n_chunks = host.tolist()
+            self._pending = None
+            if status != 0:
+                raise nv.SpmiError(f"edge list holds a node id outside [0, {self.n_rows}) / "
+                                   f"[0, {self.n_cols})")
+        return self
+
+    @property
+    def n_heavy(self) -> int:
+        return self.ready()._n_heavy
+
+    @property
+    def n_chunks(self) -> int:
+        return self.ready()._n_chunks
 
     def partial_ws(self, feat: int) -> Optional[torch.Tensor]:
         if self.n_heavy == 0:
@@ -94,12 +115,23 @@ def _plan(indptr: torch.Tensor, n_rows: int, e: int, meta: torch.Tensor, heavy_t
     return heavy_rows, heavy_ptr
 
 
+def _fetch_meta(meta: torch.Tensor):
+    """Queue the copy of a build's (status, n_heavy, n_chunks) to pinned host memory and an
+    event behind it; the device tensor rides along so its memory outlives the copy."""
+    host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+    host.copy_(meta, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return host, event, meta
+
+
 def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
-              want_eid: bool = False) -> CSR:
-    """COO -> CSR grouped by `key` plus the aggregation plan (one host sync to read the
-    status word and the plan sizes).  Edge ids travel through the sort only when
-    `want_eid` (edge weights / edge features need them; plain GCN does not)."""
+              want_eid: bool = False, defer: bool = False) -> CSR:
+    """COO -> CSR grouped by `key` plus the aggregation plan.  The status word and the plan
+    sizes cost one host sync: here, or with `defer` at the CSR's first `ready()`.  Edge ids
+    travel through the sort only when `want_eid` (edge weights / edge features need them;
+    plain GCN does not)."""
     nv.require_cuda(key, other)
     key, other = _i64(key).contiguous(), _i64(other).contiguous()
     dev = key.device
@@ -116,11 +148,10 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
                                      nv.ptr(indices), nv.ptr(eid), nv.ptr(ws), ws_bytes,
                                      nv.ptr(meta), nv.stream()), "spmi_coo_to_csr")
         heavy_rows, heavy_ptr = _plan(indptr, n_key, e, meta, heavy_thresh, chunk)
-        status, n_heavy, n_chunks = meta.tolist()
-    if status != 0:
-        raise nv.SpmiError(f"edge list holds a node id outside [0, {n_key}) / [0, {n_other})")
-    return CSR(indptr, indices, eid, n_key, n_other, e, heavy_rows, heavy_ptr, n_heavy, n_chunks,
-               heavy_thresh, chunk)
+        pending = _fetch_meta(meta)
+    csr = CSR(indptr, indices, eid, n_key, n_other, e, heavy_rows, heavy_ptr, 0, 0, heavy_thresh,
+              chunk, pending)
+    return csr if defer else csr.ready()
 
 
 class CumulativeCSR:
@@ -138,7 +169,8 @@ class CumulativeCSR:
                                f"({self.full.nnz} edges, {self.full.n_rows} rows)")
 
     def prefix(self, e_cut: int, n_rows: int, n_cols: int, want_eid: bool = False,
-               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK) -> CSR:
+               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
+               defer: bool = False) -> CSR:
         """CSR of the first `e_cut` edges over rows [0, n_rows): bit-identical to
         `build_csr(key[:e_cut], other[:e_cut], n_rows, n_cols)`."""
         self._check(e_cut, n_rows)
@@ -156,11 +188,10 @@ class CumulativeCSR:
                                          nv.ptr(eid), nv.ptr(ws), ws_bytes, nv.ptr(meta),
                                          nv.stream()), "spmi_csr_prefix")
             heavy_rows, heavy_ptr = _plan(indptr, n_rows, e_cut, meta, heavy_thresh, chunk)
-            status, n_heavy, n_chunks = meta.tolist()
-        if status != 0:
-            raise nv.SpmiError(f"edge list holds a node id outside [0, {n_rows}) / [0, {n_cols})")
-        return CSR(indptr, indices, eid, n_rows, n_cols, e_cut, heavy_rows, heavy_ptr, n_heavy,
-                   n_chunks, heavy_thresh, chunk)
+            pending = _fetch_meta(meta)
+        csr = CSR(indptr, indices, eid, n_rows, n_cols, e_cut, heavy_rows, heavy_ptr, 0, 0,
+                  heavy_thresh, chunk, pending)
+        return csr if defer else csr.ready()
 
     def prefix_degree(self, e_cut: int, n_rows: int) -> torch.Tensor:
         """int64 degrees of rows [0, n_rows) in the first `e_cut` edges."""
@@ -174,8 +205,10 @@ class CumulativeCSR:
         return out
 
 
-def degree(ids: torch.Tensor, n: int) -> torch.Tensor:
-    """deg[v] = occurrences of v in ids (int64), by keys-only sort + run boundaries."""
+def degree(ids: torch.Tensor, n: int, validated: bool = False) -> torch.Tensor:
+    """deg[v] = occurrences of v in ids (int64), by keys-only sort + run boundaries.
+    `validated` says the caller already knows every id is inside [0, n), so the call does
+    not wait for the device to report the range check."""
     nv.require_cuda(ids)
     ids = _i64(ids).contiguous()
     dev = ids.device
@@ -187,8 +220,19 @@ def degree(ids: torch.Tensor, n: int) -> torch.Tensor:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         nv.check(lib.spmi_degree(nv.ptr(ids), ids.numel(), n, nv.ptr(out), nv.ptr(ws), ws_bytes,
                                  nv.ptr(status), nv.stream()), "spmi_degree")
-        if status.item() != 0:
+        if not validated and status.item() != 0:
             raise nv.SpmiError(f"node id outside [0, {n})")
+    return out
+
+
+def norm_from_degree(deg: torch.Tensor, mode: int) -> torch.Tensor:
+    """clamp(deg, 1)^-0.5 (mode 0) or 1/clamp(deg, 1) (mode 1) as fp32, one launch."""
+    nv.require_cuda(deg)
+    deg = _i64(deg).contiguous()
+    with torch.cuda.device(deg.device):
+        out = torch.empty(deg.numel(), dtype=torch.float32, device=deg.device)
+        nv.check(nv.lib().spmi_norm_from_degree(nv.ptr(deg), deg.numel(), mode, nv.ptr(out),
+                                                nv.stream()), "spmi_norm_from_degree")
     return out
 
 
@@ -266,10 +310,11 @@ class NormalisedAdjacency:
         cache = self._edge_scale_cache()
         w = cache.get(key)
         if w is None and scaled:
-            csr = self.csr() if direction == "fwd" else self.csr_t()
+            csr = self.csr(wait=False) if direction == "fwd" else self.csr_t(wait=False)
             w = cache[key] = self.norm(side, mode).index_select(0, csr.indices)
         if edge_weight is not None:
-            csr = self.csr(want_eid=True) if direction == "fwd" else self.csr_t(want_eid=True)
+            csr = (self.csr(want_eid=True, wait=False) if direction == "fwd"
+                   else self.csr_t(want_eid=True, wait=False))
             p = edge_weight.detach().to(torch.float32).reshape(-1).index_select(0, csr.eid)
             w = p if w is None else w * p
         return w
@@ -375,7 +420,8 @@ class SnapshotGraph(NormalisedAdjacency):
             if self._table is not None:
                 self._out_deg = self._table.by_src().prefix_degree(self._src.numel(), self._n)
             else:
-                self._out_deg = degree(self._src, self._n)
+                # the by-destination build has range-checked both id arrays
+                self._out_deg = degree(self._src, self._n, validated=self._csr is not None)
         return self._out_deg
 
     def add_self_loop(self) -> "SnapshotGraph":
@@ -420,22 +466,27 @@ class SnapshotGraph(NormalisedAdjacency):
         return csr.indices[lo:hi].to(torch.int64)
 
     # ---- device structures ------------------------------------------------------------
-    def csr(self, want_eid: bool = False) -> CSR:
+    def csr(self, want_eid: bool = False, wait: bool = True) -> CSR:
+        """By-destination CSR.  `wait=False` returns it with its status word and plan sizes
+        still in flight (CSR.ready() collects them; every aggregation does)."""
         if self._csr is None or (want_eid and self._csr.eid is None):
             if self._table is not None and self._src.numel() > 0:
-                self._csr = self._table.by_dst().prefix(self._src.numel(), self._n, self._n, want_eid)
+                self._csr = self._table.by_dst().prefix(self._src.numel(), self._n, self._n, want_eid,
+                                                        defer=True)
             else:
-                self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid)
-        return self._csr
+                self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid,
+                                      defer=True)
+        return self._csr.ready() if wait else self._csr
 
-    def csr_t(self, want_eid: bool = False) -> CSR:
+    def csr_t(self, want_eid: bool = False, wait: bool = True) -> CSR:
         if self._csr_t is None or (want_eid and self._csr_t.eid is None):
             if self._table is not None and self._src.numel() > 0:
                 self._csr_t = self._table.by_src().prefix(self._src.numel(), self._n, self._n,
-                                                          want_eid)
+                                                          want_eid, defer=True)
             else:
-                self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid)
-        return self._csr_t
+                self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid,
+                                        defer=True)
+        return self._csr_t.ready() if wait else self._csr_t
 
     def norm(self, side: str, mode: int) -> torch.Tensor:
         """GraphConv normaliser: side 'in' (destination, in-degree) or 'out' (source,
@@ -443,12 +494,14 @@ class SnapshotGraph(NormalisedAdjacency):
         key = (side, mode)
         if key not in self._norms:
             if side == "in":
-                self._norms[key] = self.csr().norm(mode)
+                self._norms[key] = self.csr(wait=False).norm(mode)
             elif self._csr_t is not None or torch.is_grad_enabled():
-                self._norms[key] = self.csr_t().norm(mode)
+                self._norms[key] = self.csr_t(wait=False).norm(mode)
             else:
-                degs = self.out_degrees().to(torch.float32).clamp_(min=1)
-                self._norms[key] = degs.sqrt_().reciprocal_() if mode == 0 else degs.reciprocal_()
+                # The by-destination build range-checks both id arrays, and the aggregation
+                # that uses this normaliser collects its verdict.
+                self.csr(wait=False)
+                self._norms[key] = norm_from_degree(self.out_degrees(), mode)
         return self._norms[key]
 
 

@@ -49,7 +49,7 @@ class GcnAggregate(torch.autograd.Function):
     def forward(ctx, x, bias, g, norm, edge_weight, act, slope):
         mode = 0 if norm in ("both", "sgc") else 1
         dst_scale = g.norm("in", mode) if norm in ("right", "both", "sgc") else None
-        y = aggregate(g.csr(), x.detach(), None, g.edge_scale("fwd", norm, edge_weight), dst_scale,
+        y = aggregate(g.csr(wait=False), x.detach(), None, g.edge_scale("fwd", norm, edge_weight), dst_scale,
                       None if bias is None else bias.detach(), act, slope)
         ctx.g, ctx.norm, ctx.edge_weight, ctx.act, ctx.slope = g, norm, edge_weight, act, slope
         ctx.has_bias = bias is not None
@@ -70,7 +70,7 @@ class GcnAggregate(torch.autograd.Function):
             out_scale = g.norm("out", mode) if norm in ("left", "both") else None
             if norm == "sgc":
                 out_scale = g.norm("in", mode)
-            g_x = aggregate(g.csr_t(), g_p.contiguous(), None,
+            g_x = aggregate(g.csr_t(wait=False), g_p.contiguous(), None,
                             g.edge_scale("bwd", norm, ctx.edge_weight), out_scale, None, None)
         return g_x, g_b, None, None, None, None, None
 

@@ -124,13 +124,13 @@ class ShardedSnapshot(G.NormalisedAdjacency):
         keep = (dst >= lo) & (dst < hi)
         return cls(src[keep], dst[keep], part, group)
 
-    def csr(self, want_eid: bool = False):
+    def csr(self, want_eid: bool = False, wait: bool = True):
         if self._csr is None:
             self._csr = kernels.build_csr(self.dst_rows, self.src_rows, self.n_local,
                                           self.part.n_gather)
         return self._csr
 
-    def csr_t(self, want_eid: bool = False):
+    def csr_t(self, want_eid: bool = False, wait: bool = True):
         if self._csr_t is None:
             self._csr_t = kernels.build_csr(self.src_rows, self.dst_rows, self.part.n_gather,
                                             self.n_local)

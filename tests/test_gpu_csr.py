@@ -73,6 +73,36 @@ def test_out_of_range_id_is_reported(dev):
         G.degree(torch.tensor([-1, 2], dtype=torch.int64, device=dev), 5)
 
 
+def test_deferred_build_reports_at_first_use(dev):
+    """A CSR built with defer=True hands back control before the device has answered; the
+    verdict on the ids arrives with ready(), and so with any aggregation on the graph."""
+    good_src = torch.tensor([0, 1, 2], dtype=torch.int64, device=dev)
+    good_dst = torch.tensor([1, 2, 4], dtype=torch.int64, device=dev)
+    csr = G.build_csr(good_dst, good_src, 5, 5, defer=True)
+    assert csr._pending is not None
+    assert (csr.n_heavy, csr.n_chunks) == (0, 0) and csr._pending is None
+    bad = G.build_csr(torch.tensor([0, 1, 9], dtype=torch.int64, device=dev), good_src, 5, 5, defer=True)
+    with pytest.raises(nv.SpmiError):
+        bad.ready()
+    g = G.SnapshotGraph(good_src, torch.tensor([0, 1, 9], dtype=torch.int64, device=dev), 5)
+    x = torch.ones(5, 4, device=dev)
+    from spiral_amd import ops
+    with pytest.raises(nv.SpmiError), torch.no_grad():
+        ops.gcn_aggregate(g, x, "both")
+    g2 = G.SnapshotGraph(torch.tensor([0, 7, 2], dtype=torch.int64, device=dev), good_dst, 5)
+    with pytest.raises(nv.SpmiError), torch.no_grad():
+        ops.gcn_aggregate(g2, x, "both")     # the bad id sits on the source side
+    with pytest.raises(nv.SpmiError):
+        g2.csr()                              # the waiting accessor reports it too
+
+
+def test_norm_from_degree(dev):
+    deg = torch.tensor([0, 1, 2, 4, 9, 1_000_000], dtype=torch.int64, device=dev)
+    want = deg.to(torch.float32).clamp(min=1)
+    assert torch.equal(G.norm_from_degree(deg, 0), 1.0 / want.sqrt())
+    assert torch.equal(G.norm_from_degree(deg, 1), 1.0 / want)
+
+
 def test_plan_lists_exactly_the_heavy_rows(dev):
     n, e = 20_000, 400_000
     src, dst = orc.powerlaw_snapshot(n, e, t=1, k_dst=6.0)
