@@ -300,7 +300,7 @@ def main():
             from spiral_amd.dtdg.types import Snapshot
 
             g = G.SnapshotGraph(src, dst, n_total)
-            g.csr()
+            g.csr(wait=False)  # the first aggregation collects the build's status word
             g.norm("in", 0)
             g.norm("out", 0)
             g.ndata["h"] = x_local
@@ -315,7 +315,7 @@ def main():
             return h
         if world == 1:
             g = G.SnapshotGraph(src, dst, n_total)
-            g.csr()
+            g.csr(wait=False)  # the first aggregation collects the build's status word
             g.norm("in", 0)
             g.norm("out", 0)
             if record:
@@ -526,9 +526,11 @@ def main():
                        "head": "one-kernel inference MLP" if MLP.FUSE_EVAL and not train else "torch layers",
                        "host": ("python gc left running" if args.no_gc_freeze
                                 else "gc.collect() + gc.freeze() after warm-up, before the timed region"),
-                       "gate_gemm": ("fp32 results from bf16 matrix cores: operands split exactly in three "
-                                     "bf16 pieces, six piece products per term"
-                                     if ops.CELL_GEMM == "bf16x3" else "fp32 matrix instruction"),
+                       "gate_gemm": {"f16x3": "fp32 results from the fp16 matrix cores: operands as fp16(v), fp16(v/64), "
+                                              "fp16((v - fp16(v))*64), three products per term",
+                                     "bf16x3": "fp32 results from bf16 matrix cores: operands split exactly in "
+                                               "three bf16 pieces, six piece products per term",
+                                     "fp32": "fp32 matrix instruction"}[ops.CELL_GEMM],
                        "exchange": exchange_note or (args.exchange if world > 1 and not train else
                                                      ("plain" if world > 1 else None)),
                        "parallelism": (f"dst-row blocks x{world}, all-gather per layer" +

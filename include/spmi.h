@@ -263,6 +263,23 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
                         float* c_out, int mem_write, float* saved, void* stream);
 
+/* Same layer step (same reference lines as spmi_cell_fused_fwd) with half the matrix work
+ * of spmi_cell_split_fwd: three fp16 matrix instructions per term instead of six bf16 ones.
+ * An operand v travels as p0 = fp16(v), p1 = fp16(v / 64), p2 = fp16((v - p0) * 64) and
+ * x*w = p0(x)*p0(w) + p1(x)*p2(w) + p2(x)*p1(w) with fp32 accumulation: each product is off
+ * by at most about 2^-20 |x w|, and sums of 256 terms measure 3-8x closer to float64 than an
+ * fp32 FMA chain.  Domain: |v| <= 65504 for x, the state and the weights; a larger operand
+ * turns into infinity and its output row into inf/NaN (spmi_cell_split_fwd has no such
+ * limit).  ws_ih / ws_hh come from spmi_split_f16x3 (same tiling as spmi_split_bf16x3:
+ * [cols/16][3][rows][16] 16-bit words).  Arguments and shape limits as
+ * spmi_cell_split_fwd. */
+int spmi_split_f16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
+                       void* out /*device 16-bit words, 3*rows*cols*/, void* stream);
+int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
+                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream);
+
 /* ------------------------------------------------------------------------
  * Attention encoder.  Replace what dgl GATConv.forward runs on the graph
  * (reference call sites: GAT in staticGraphEncoder.py:170,174,190):

@@ -11,7 +11,7 @@ for kind, g in (('gru', 3), ('lstm', 4), ('rnn', 1)):
     b_ih = torch.randn(g*h, device=dev) * 0.1; b_hh = torch.randn(g*h, device=dev) * 0.1
     mem0 = torch.randn(n, h, device=dev); c0 = torch.randn(n, h, device=dev)
     outs = {}
-    for mode in ('fp32', 'bf16x3'):
+    for mode in ('fp32', 'bf16x3', 'f16x3'):
         ops.CELL_GEMM = mode
         mh, mc = mem0.clone(), c0.clone()
         with torch.no_grad():

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--h", type=int, default=128)
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--gemm", default="bf16x3", choices=["bf16x3", "fp32"])
+    ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "bf16x3", "fp32"])
     a = ap.parse_args()
     ops.CELL_GEMM = a.gemm
     dev = torch.device("cuda:0")

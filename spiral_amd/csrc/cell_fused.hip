@@ -84,7 +84,7 @@ __device__ __forceinline__ float sigmoidf_(float v) {
   return __frcp_rn(1.0f + __expf(-v));
 }
 __device__ __forceinline__ float tanhf_(float v) {
-  const float e = __expf(2.0f * fminf(v, 15.0f));  // tanh saturates to 1 in fp32 beyond ~9
+  const float e = __expf(2.0f * (v > 15.0f ? 15.0f : v));  // saturates beyond ~9; NaN stays NaN
   return (e - 1.0f) * __frcp_rn(e + 1.0f);
 }
 

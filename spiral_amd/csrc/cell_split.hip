@@ -8,6 +8,20 @@
 // tests), while six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight
 // v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x the matrix rate.
 //
+// A second operand format (MODE_F16X3) halves the matrix work again: three fp16 planes
+//     p0 = fp16(v),   p1 = fp16(v * 2^-6),   p2 = fp16((v - p0) * 2^6)
+// and three v_mfma_f32_32x32x16_f16 per term,
+//     x*w  =  p0(x)*p0(w)  +  p1(x)*p2(w)  +  p2(x)*p1(w).
+// With x = xh + xl, w = wh + wl (xh = p0(x), xl = x - xh exactly, |xl| <= 2^-11 |x|) the
+// exact product is xh*wh + x*wl + xl*wh, and the last two terms are what the scaled planes
+// carry (2^-6 * 2^6 = 1): each factor is rounded to 11 bits once, so a product is off by at
+// most about 2^-20 |xw|.  The scaling keeps the small planes out of fp16's subnormal range
+// for |v| down to about 2^-8; below that they lose relative but not absolute accuracy (the
+// matrix cores keep subnormal fp16 inputs, scripts/probe/mfma_f16_denorm.hip).  Measured
+// against float64 the sums are 3-8x closer than an fp32 FMA chain of the same length.
+// Domain: |v| <= 65504.  A larger operand becomes infinity in p0 and the output of its row
+// is inf/NaN, as in any fp16 matrix pipeline; the bf16x3 mode has no such limit.
+//
 // Replaces the same reference lines as cell_fused.hip: torch.nn.GRU / LSTM / RNN as driven
 // by SequentialDecoder.forward / LSTM.forward (spiro/dtdg/models/decoder/torch/
 // sequentialDecoder/implicitTimeModels.py:144-158, :214-230) with NodeMemory.get_memory /
@@ -33,6 +47,10 @@ constexpr int kBK = 16;
 using f32x16 = float __attribute__((ext_vector_type(16)));
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
+
+enum { MODE_BF16X3 = 0, MODE_F16X3 = 1 };
 
 enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_RNN = 2 };
 
@@ -78,7 +96,7 @@ struct SplitArgs {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float tanhf_(float v) {
-  const float e = __expf(2.0f * fminf(v, 15.0f));
+  const float e = __expf(2.0f * (v > 15.0f ? 15.0f : v));  // NaN stays NaN
   return (e - 1.0f) * __frcp_rn(e + 1.0f);
 }
 
@@ -90,20 +108,40 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
   lo = static_cast<__bf16>(r1 - static_cast<float>(mid));
 }
 
+// p0 = fp16(v), p1 = fp16(v / 64), p2 = fp16((v - p0) * 64).
+__device__ __forceinline__ void split_f16x3(float v, _Float16& p0, _Float16& p1, _Float16& p2) {
+  p0 = static_cast<_Float16>(v);
+  p1 = static_cast<_Float16>(v * 0x1p-6f);
+  p2 = static_cast<_Float16>((v - static_cast<float>(p0)) * 0x1p6f);
+}
+
 // Weights [rows][cols] fp32 -> [cols/16][3 pieces][rows][16] bf16: for one K-step the three
 // piece images of all rows are one contiguous block in the order the LDS stage wants them,
 // so the staging loads are fully coalesced.
-__global__ void split_bf16x3_kernel(const float* __restrict__ w, int64_t rows, int64_t cols,
-                                    __bf16* __restrict__ out) {
+template <int MODE>
+__global__ void split_weights_kernel(const float* __restrict__ w, int64_t rows, int64_t cols,
+                                     uint16_t* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int64_t n = i / cols, k = i % cols;
-  __bf16 hi, mid, lo;
-  split3(w[i], hi, mid, lo);
+  uint16_t q0, q1, q2;
+  if constexpr (MODE == MODE_F16X3) {
+    _Float16 p0, p1, p2;
+    split_f16x3(w[i], p0, p1, p2);
+    q0 = __builtin_bit_cast(uint16_t, p0);
+    q1 = __builtin_bit_cast(uint16_t, p1);
+    q2 = __builtin_bit_cast(uint16_t, p2);
+  } else {
+    __bf16 hi, mid, lo;
+    split3(w[i], hi, mid, lo);
+    q0 = __builtin_bit_cast(uint16_t, hi);
+    q1 = __builtin_bit_cast(uint16_t, mid);
+    q2 = __builtin_bit_cast(uint16_t, lo);
+  }
   const int64_t base = (k / 16) * 3 * rows * 16 + n * 16 + (k % 16);
-  out[base] = hi;
-  out[base + rows * 16] = mid;
-  out[base + 2 * rows * 16] = lo;
+  out[base] = q0;
+  out[base + rows * 16] = q1;
+  out[base + 2 * rows * 16] = q2;
 }
 
 template <int APT, int BPT>
@@ -129,24 +167,39 @@ __device__ __forceinline__ void load_stage(StageRegs<APT, BPT>& r, const float* 
   }
 }
 
-template <int APT, int BPT, int B16, int THREADS, int A_PLANE, int A_BYTES>
+template <int MODE, int APT, int BPT, int B16, int THREADS, int A_PLANE, int A_BYTES>
 __device__ __forceinline__ void store_stage(const StageRegs<APT, BPT>& r, char* stage,
                                             const int (&a_dst)[APT], int tid) {
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
-    bf16x4 hi, mid, lo;
     const float v[4] = {r.a[i].x, r.a[i].y, r.a[i].z, r.a[i].w};
+    if constexpr (MODE == MODE_F16X3) {
+      f16x4 p0, p1, p2;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __bf16 h1, m1, l1;
-      split3(v[q], h1, m1, l1);
-      hi[q] = h1;
-      mid[q] = m1;
-      lo[q] = l1;
+      for (int q = 0; q < 4; ++q) {
+        _Float16 h1, m1, l1;
+        split_f16x3(v[q], h1, m1, l1);
+        p0[q] = h1;
+        p1[q] = m1;
+        p2[q] = l1;
+      }
+      *reinterpret_cast<f16x4*>(stage + a_dst[i]) = p0;
+      *reinterpret_cast<f16x4*>(stage + A_PLANE + a_dst[i]) = p1;
+      *reinterpret_cast<f16x4*>(stage + 2 * A_PLANE + a_dst[i]) = p2;
+    } else {
+      bf16x4 hi, mid, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __bf16 h1, m1, l1;
+        split3(v[q], h1, m1, l1);
+        hi[q] = h1;
+        mid[q] = m1;
+        lo[q] = l1;
+      }
+      *reinterpret_cast<bf16x4*>(stage + a_dst[i]) = hi;
+      *reinterpret_cast<bf16x4*>(stage + A_PLANE + a_dst[i]) = mid;
+      *reinterpret_cast<bf16x4*>(stage + 2 * A_PLANE + a_dst[i]) = lo;
     }
-    *reinterpret_cast<bf16x4*>(stage + a_dst[i]) = hi;
-    *reinterpret_cast<bf16x4*>(stage + A_PLANE + a_dst[i]) = mid;
-    *reinterpret_cast<bf16x4*>(stage + 2 * A_PLANE + a_dst[i]) = lo;
   }
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
@@ -159,7 +212,7 @@ __device__ __forceinline__ void store_stage(const StageRegs<APT, BPT>& r, char* 
 // The MFMAs of one K-step (16) of one wave: three A fragments, then per 32-column block
 // three B fragments and the six piece products, smallest terms first.  The next block's
 // fragments are read while the current block's MFMAs issue.
-template <int CELL, int JSUB, int JC, int A_PLANE, int B_PLANE, bool HPHASE>
+template <int MODE, int CELL, int JSUB, int JC, int A_PLANE, int B_PLANE, bool HPHASE>
 __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC], const char* sa,
                                            const char* sb) {
   using C = Cell<CELL>;
@@ -185,12 +238,24 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
     if (PREFETCH) __builtin_amdgcn_sched_barrier(0);
     const int g = i / JSUB, sub = i % JSUB;
     const int ai = HPHASE ? C::acc_h[g] : C::acc_x[g];
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b_cur[0], acc[sub][ai], 0, 0, 0);
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[2], acc[sub][ai], 0, 0, 0);
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[1], acc[sub][ai], 0, 0, 0);
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[0], acc[sub][ai], 0, 0, 0);
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[1], acc[sub][ai], 0, 0, 0);
-    acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[0], acc[sub][ai], 0, 0, 0);
+    if constexpr (MODE == MODE_F16X3) {
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a2),
+                                                           __builtin_bit_cast(f16x8, b_cur[1]),
+                                                           acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1),
+                                                           __builtin_bit_cast(f16x8, b_cur[2]),
+                                                           acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0),
+                                                           __builtin_bit_cast(f16x8, b_cur[0]),
+                                                           acc[sub][ai], 0, 0, 0);
+    } else {
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b_cur[0], acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[2], acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[1], acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b_cur[0], acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[1], acc[sub][ai], 0, 0, 0);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b_cur[0], acc[sub][ai], 0, 0, 0);
+    }
     if (PREFETCH) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -203,7 +268,7 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
   }
 }
 
-template <int CELL, int JSUB, int WC, bool IDS>
+template <int MODE, int CELL, int JSUB, int WC, bool IDS>
 __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel(SplitArgs p) {
   using C = Cell<CELL>;
   constexpr int THREADS = 256 * WC;
@@ -285,25 +350,25 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
     const int tiles_h = H / kBK;
     __syncthreads();  // the previous pass has finished reading both buffers
     load_stage<APT, BPT>(regs, xbase, ax, 0, p.ws_ih, boff, 0);
-    store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
+    store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
     __syncthreads();
     int buf = 0;
     for (int t = 0; t < tiles_x; ++t) {
       if (t + 1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, (t + 1) * kBK, p.ws_ih, boff, (t + 1) * bstep);
       else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
-      mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, false>(acc, smem + buf * STAGE + a_rd,
+      mfma_stage<MODE, CELL, JSUB, JC, A_PLANE, B_PLANE, false>(acc, smem + buf * STAGE + a_rd,
                                                           smem + buf * STAGE + b_rd);
-      store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
+      store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
       __syncthreads();
       buf ^= 1;
     }
     for (int t = 0; t < tiles_h; ++t) {
       const bool more = t + 1 < tiles_h;
       if (more) load_stage<APT, BPT>(regs, hbase, ah, (t + 1) * kBK, p.ws_hh, boff, (t + 1) * bstep);
-      mfma_stage<CELL, JSUB, JC, A_PLANE, B_PLANE, true>(acc, smem + buf * STAGE + a_rd,
+      mfma_stage<MODE, CELL, JSUB, JC, A_PLANE, B_PLANE, true>(acc, smem + buf * STAGE + a_rd,
                                                          smem + buf * STAGE + b_rd);
       if (more)
-        store_stage<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
+        store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
       __syncthreads();
       buf ^= 1;
     }
@@ -340,8 +405,16 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
         }
         if constexpr (CELL == CELL_GRU) {
           const float h = hm[voff];
-          const float r = sigmoidf_(acc[s][0][e] + (bi[0] + bhh[0]));
-          const float z = sigmoidf_(acc[s][1][e] + (bi[1] + bhh[1]));
+          // r and z from one reciprocal: with p = 1 + e^-a, q = 1 + e^-b and i = 1/(p q),
+          // r = q i and z = p i.  The exponents are clamped at 40 so that p q stays finite
+          // (sigmoid(-40) = 4e-18 is already 0 next to anything it is added to).
+          const float ar = acc[s][0][e] + (bi[0] + bhh[0]);
+          const float az = acc[s][1][e] + (bi[1] + bhh[1]);
+          const float pr = 1.0f + __expf(ar < -40.0f ? 40.0f : -ar);
+          const float pz = 1.0f + __expf(az < -40.0f ? 40.0f : -az);
+          const float inv = __frcp_rn(pr * pz);
+          const float r = pz * inv;
+          const float z = pr * inv;
           const float hn = acc[s][3][e] + bhh[2];
           const float n = tanhf_(acc[s][2][e] + bi[2] + r * hn);
           const float hy = n + z * (h - n);
@@ -397,13 +470,13 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
   }
 }
 
-template <int CELL, int JSUB, int WC>
+template <int MODE, int CELL, int JSUB, int WC>
 int launch_config(const SplitArgs& a, hipStream_t st) {
   constexpr int NC = Cell<CELL>::NG * JSUB * 32 * WC;
   constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2);
   static_assert(lds <= 160 * 1024, "LDS stage does not fit");
-  auto plain = split_cell_kernel<CELL, JSUB, WC, false>;
-  auto gathered = split_cell_kernel<CELL, JSUB, WC, true>;
+  auto plain = split_cell_kernel<MODE, CELL, JSUB, WC, false>;
+  auto gathered = split_cell_kernel<MODE, CELL, JSUB, WC, true>;
   static bool configured = false;
   if (!configured) {
     SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plain),
@@ -419,50 +492,48 @@ int launch_config(const SplitArgs& a, hipStream_t st) {
   return SPMI_OK;
 }
 
-template <int CELL>
+template <int MODE, int CELL>
 int launch_split(const SplitArgs& a, hipStream_t st) {
-  if (a.H % 128 == 0) return launch_config<CELL, 2, 2>(a, st);
-  if (a.H % 64 == 0) return launch_config<CELL, 1, 2>(a, st);
-  return launch_config<CELL, 1, 1>(a, st);
+  if (a.H % 128 == 0) return launch_config<MODE, CELL, 2, 2>(a, st);
+  if (a.H % 64 == 0) return launch_config<MODE, CELL, 1, 2>(a, st);
+  return launch_config<MODE, CELL, 1, 1>(a, st);
 }
 
-}  // namespace
-
-extern "C" {
-
-int spmi_split_bf16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
+template <int MODE>
+int split_weights(const float* w, int64_t rows, int64_t cols, void* out, void* stream,
+                  const char* name) {
   SPMI_REQUIRE(rows >= 1 && cols >= 16 && cols % 16 == 0 && w && out, SPMI_ERR_INVALID_ARG,
-               "spmi_split_bf16x3: needs rows >= 1, cols a multiple of 16 and non-null pointers");
+               "%s: needs rows >= 1, cols a multiple of 16 and non-null pointers", name);
   const int64_t n = rows * cols;
-  split_bf16x3_kernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(
-      w, rows, cols, static_cast<__bf16*>(out));
-  SPMI_CHECK_LAUNCH("split_bf16x3");
+  split_weights_kernel<MODE><<<static_cast<unsigned>((n + 255) / 256), 256, 0,
+                               spmi::as_stream(stream)>>>(w, rows, cols, static_cast<uint16_t*>(out));
+  SPMI_CHECK_LAUNCH(name);
   return SPMI_OK;
 }
 
-int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
-                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
-                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
-                        float* c_out, int mem_write, float* saved, void* stream) {
-  SPMI_REQUIRE(cell >= CELL_GRU && cell <= CELL_RNN, SPMI_ERR_INVALID_ARG,
-               "spmi_cell_split_fwd: bad cell code %d", cell);
-  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
-               "spmi_cell_split_fwd: bad M=%lld", (long long)M);
+template <int MODE>
+int cell_split_fwd(const char* name, int cell, const float* x, int64_t ldx, int64_t I,
+                   const void* ws_ih, const void* ws_hh, const float* b_ih, const float* b_hh,
+                   float* h_mem, float* c_mem, const int64_t* ids, int64_t M, int64_t H,
+                   float* h_out, float* c_out, int mem_write, float* saved, void* stream) {
+  SPMI_REQUIRE(cell >= CELL_GRU && cell <= CELL_RNN, SPMI_ERR_INVALID_ARG, "%s: bad cell code %d",
+               name, cell);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "%s: bad M=%lld", name,
+               (long long)M);
   SPMI_REQUIRE(I >= 32 && I % 32 == 0 && H >= 32 && H % 32 == 0 && I <= 8192 && H <= 8192,
-               SPMI_ERR_UNSUPPORTED,
-               "spmi_cell_split_fwd: needs I %% 32 == 0 and H %% 32 == 0 (I=%lld H=%lld)",
+               SPMI_ERR_UNSUPPORTED, "%s: needs I %% 32 == 0 and H %% 32 == 0 (I=%lld H=%lld)", name,
                (long long)I, (long long)H);
   SPMI_REQUIRE(ldx < (int64_t{1} << 20), SPMI_ERR_UNSUPPORTED,
-               "spmi_cell_split_fwd: leading dimension %lld too large", (long long)ldx);
+               "%s: leading dimension %lld too large", name, (long long)ldx);
   if (M == 0) return SPMI_OK;
   SPMI_REQUIRE(x && ws_ih && ws_hh && h_mem && h_out && ldx >= I && ldx % 4 == 0,
-               SPMI_ERR_INVALID_ARG, "spmi_cell_split_fwd: null pointer or bad ldx");
+               SPMI_ERR_INVALID_ARG, "%s: null pointer or bad ldx", name);
   SPMI_REQUIRE(cell != CELL_LSTM || (c_mem && c_out), SPMI_ERR_INVALID_ARG,
-               "spmi_cell_split_fwd: LSTM needs c_mem and c_out");
+               "%s: LSTM needs c_mem and c_out", name);
   for (const void* q : {(const void*)x, ws_ih, ws_hh, (const void*)h_mem, (const void*)h_out,
                         (const void*)c_mem, (const void*)c_out})
     SPMI_REQUIRE(!q || (reinterpret_cast<uintptr_t>(q) & 15u) == 0, SPMI_ERR_INVALID_ARG,
-                 "spmi_cell_split_fwd: pointers must be 16-byte aligned");
+                 "%s: pointers must be 16-byte aligned", name);
   SplitArgs a{};
   a.x = x; a.ldx = ldx; a.I = static_cast<int>(I);
   a.ws_ih = static_cast<const __bf16*>(ws_ih); a.ws_hh = static_cast<const __bf16*>(ws_hh);
@@ -470,9 +541,37 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
   a.h_mem = h_mem; a.c_mem = c_mem; a.ids = ids; a.M = M; a.H = static_cast<int>(H);
   a.h_out = h_out; a.c_out = c_out; a.mem_write = mem_write; a.saved = saved;
   hipStream_t st = spmi::as_stream(stream);
-  if (cell == CELL_GRU) return launch_split<CELL_GRU>(a, st);
-  if (cell == CELL_LSTM) return launch_split<CELL_LSTM>(a, st);
-  return launch_split<CELL_RNN>(a, st);
+  if (cell == CELL_GRU) return launch_split<MODE, CELL_GRU>(a, st);
+  if (cell == CELL_LSTM) return launch_split<MODE, CELL_LSTM>(a, st);
+  return launch_split<MODE, CELL_RNN>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmi_split_bf16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
+  return split_weights<MODE_BF16X3>(w, rows, cols, out, stream, "spmi_split_bf16x3");
+}
+
+int spmi_split_f16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
+  return split_weights<MODE_F16X3>(w, rows, cols, out, stream, "spmi_split_f16x3");
+}
+
+int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
+                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream) {
+  return cell_split_fwd<MODE_BF16X3>("spmi_cell_split_fwd", cell, x, ldx, I, ws_ih, ws_hh, b_ih, b_hh,
+                                     h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, stream);
+}
+
+int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
+                        const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
+                        float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
+                        float* c_out, int mem_write, float* saved, void* stream) {
+  return cell_split_fwd<MODE_F16X3>("spmi_cell_f16x3_fwd", cell, x, ldx, I, ws_ih, ws_hh, b_ih, b_hh,
+                                    h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, stream);
 }
 
 }  // extern "C"

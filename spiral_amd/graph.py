@@ -61,6 +61,7 @@ class CSR:
         self.heavy_rows, self.heavy_chunk_ptr = heavy_rows, heavy_chunk_ptr
         self._n_heavy, self._n_chunks = n_heavy, n_chunks
         self.heavy_thresh, self.chunk = heavy_thresh, chunk
+        self._bad_ids = False
         self._pending = pending  # (pinned int32[3], event, device int32[3]) until ready()
         self._partial: Dict[int, torch.Tensor] = {}
 
@@ -70,9 +71,10 @@ class CSR:
             event.synchronize()
             status, self._n_heavy, self._n_chunks = host.tolist()
             self._pending = None
-            if status != 0:
-                raise nv.SpmiError(f"edge list holds a node id outside [0, {self.n_rows}) / "
-                                   f"[0, {self.n_cols})")
+            self._bad_ids = status != 0
+        if self._bad_ids:  # every later use reports it again
+            raise nv.SpmiError(f"edge list holds a node id outside [0, {self.n_rows}) / "
+                               f"[0, {self.n_cols})")
         return self
 
     @property

@@ -383,10 +383,15 @@ def _fused_ok(x, w_hh) -> bool:
             and bool(nv.lib().spmi_cell_fused_supported(x.shape[1], w_hh.shape[1])))
 
 
-# How the fused layer step multiplies: "bf16x3" = fp32 operands split exactly into three
-# bf16 pieces, six piece products per term on the bf16 matrix cores (fp32-accurate, 2.7x
-# the matrix rate); "fp32" = the fp32 matrix instruction (an exact fp32 FMA chain).
-CELL_GEMM = "bf16x3"
+# How the fused layer step multiplies:
+#   "f16x3"  = every operand as the fp16 planes fp16(v), fp16(v/64), fp16((v - fp16(v))*64);
+#              three matrix instructions per term; sums land 3-8x closer to float64 than an
+#              fp32 FMA chain.  Operands must lie within +-65504 (x, state, weights): a
+#              larger one overflows to infinity and shows up as inf/NaN in its output row;
+#   "bf16x3"  = fp32 operands split exactly into three bf16 pieces, six piece products per
+#               term (fp32-accurate over the whole fp32 range, twice the matrix work);
+#   "fp32"    = the fp32 matrix instruction (an exact fp32 FMA chain).
+CELL_GEMM = "f16x3"
 
 
 def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
@@ -401,18 +406,34 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """The weight matrix [rows, cols] as the planes fp16(w), fp16(w/64), fp16((w - fp16(w))*64),
+    tiled [cols/16, 3, rows, 16] for the three-product cell kernel."""
+    w = w.detach().contiguous()
+    rows, cols = w.shape
+    out = torch.empty(cols // 16, 3, rows, 16, dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        nv.check(nv.lib().spmi_split_f16x3(nv.ptr(w), rows, cols, nv.ptr(out), nv.stream()),
+                 "spmi_split_f16x3")
+    return out
+
+
 def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h_out, c_out, saved):
     """Both gate GEMMs + gates + memory write-back in one launch (csrc/cell_split.hip or
     csrc/cell_fused.hip, see CELL_GEMM)."""
-    if CELL_GEMM == "bf16x3":
-        ws_ih, ws_hh = split_bf16x3(w_ih), split_bf16x3(w_hh)
+    if CELL_GEMM in ("bf16x3", "f16x3"):
+        split, name = ((split_bf16x3, "spmi_cell_split_fwd") if CELL_GEMM == "bf16x3"
+                       else (split_f16x3, "spmi_cell_f16x3_fwd"))
+        ws_ih, ws_hh = split(w_ih), split(w_hh)
         with torch.cuda.device(x.device):
-            nv.check(nv.lib().spmi_cell_split_fwd(
+            nv.check(getattr(nv.lib(), name)(
                 _CELL_CODE[kind], nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh),
                 nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem), nv.ptr(ids), x.shape[0],
                 w_hh.shape[1], nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
-                nv.stream()), "spmi_cell_split_fwd")
+                nv.stream()), name)
         return
+    if CELL_GEMM != "fp32":
+        raise ValueError(f"unknown CELL_GEMM {CELL_GEMM!r}")
     wt_ih = w_ih.detach().t().contiguous()
     wt_hh = w_hh.detach().t().contiguous()
     with torch.cuda.device(x.device):

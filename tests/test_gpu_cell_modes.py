@@ -1,7 +1,8 @@
-"""The one-kernel recurrent layer step in both of its arithmetic modes, against the CPU
-oracle: "fp32" (v_mfma_f32_32x32x2_f32) and "bf16x3" (fp32 operands split exactly into
-three bf16 pieces, six piece products per term on the bf16 matrix cores).  Both must meet
-the same fp32 bar (1e-5 absolute on gate outputs, which are bounded by 1)."""
+"""The one-kernel recurrent layer step in its three arithmetic modes, against the CPU
+oracle: "fp32" (v_mfma_f32_32x32x2_f32), "bf16x3" (fp32 operands split exactly into three
+bf16 pieces, six piece products per term on the bf16 matrix cores) and "f16x3" (planes
+fp16(v), fp16(v/64), fp16((v - fp16(v))*64), three products per term).  All must meet the same fp32
+bar (1e-5 absolute on gate outputs, which are bounded by 1)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,7 @@ from spiral_amd import ops
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bf16x3", "fp32"])
+@pytest.fixture(params=["f16x3", "bf16x3", "fp32"])
 def mode(request):
     old = ops.CELL_GEMM
     ops.CELL_GEMM = request.param
@@ -66,3 +67,31 @@ def test_split_pieces_are_exact(dev):
     total = pieces.float().sum(1)                                   # [4, 96, 16]
     back = total.permute(1, 0, 2).reshape(96, 64)
     assert torch.equal(back, w)
+
+
+def test_f16x3_planes(dev):
+    """p0 + p2/64 reproduces w to ~2^-22 and p1 = w/64 to fp16 rounding, over fp16's range."""
+    w = torch.randn(96, 64, device=dev) * torch.logspace(-3, 3, 64, device=dev)
+    planes = ops.split_f16x3(w)                                     # [cols/16, 3, rows, 16]
+    assert planes.shape == (4, 3, 96, 16) and planes.dtype == torch.float16
+    un = lambda p: p.double().permute(1, 0, 2).reshape(96, 64)
+    p0, p1, p2 = un(planes[:, 0]), un(planes[:, 1]), un(planes[:, 2])
+    wd = w.double()
+    assert ((p0 + p2 / 64 - wd).abs() <= wd.abs() * 2.0 ** -21 + 2.0 ** -31).all()
+    assert ((p1 * 64 - wd).abs() <= wd.abs() * 2.0 ** -11 + 2.0 ** -19).all()
+
+
+def test_f16x3_out_of_range_operand_is_loud(dev):
+    """An operand beyond fp16's range must not produce a plausible wrong number."""
+    old, ops.CELL_GEMM = ops.CELL_GEMM, "f16x3"
+    try:
+        w_ih, w_hh, b_ih, b_hh = _params(3, 32, 32, dev, seed=1)
+        x = torch.ones(130, 32, device=dev)
+        x[7, 3] = 1.0e5
+        mem = torch.zeros(130, 32, device=dev)
+        with torch.no_grad():
+            out = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem)
+        assert not torch.isfinite(out[7]).all()
+        assert torch.isfinite(out[:7]).all() and torch.isfinite(out[8:]).all()
+    finally:
+        ops.CELL_GEMM = old
