@@ -281,6 +281,23 @@ int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_out, int mem_write, float* saved, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].
+ * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites
+ * staticGraphEncoder.py:113,116; likewise SGConv / SAGEConv's fc layers) and the Linear
+ * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} and
+ * N in {32, 64, 96, 128}.  fp32 results from the fp16 matrix cores with the three-plane
+ * operand format of spmi_cell_f16x3_fwd (same accuracy, same domain |v| <= 65504);
+ * w_planes = spmi_split_f16x3(W, N, K).  The weight planes stay in LDS and x streams from
+ * HBM straight into the matrix cores, so the kernel runs at memory speed:
+ * M*(K+N)*4 bytes.  act: 0 none, 1 relu, 2 leaky_relu(slope).  bias nullable.
+ * ---------------------------------------------------------------------- */
+int spmi_gemm_rows_supported(int64_t K, int64_t N);
+int spmi_gemm_rows(const float* x /*device [M, K], row stride ldx*/, int64_t ldx, int64_t M, int64_t K,
+                   const void* w_planes, int64_t N, const float* bias /*device [N] or null*/, int act,
+                   float slope, float* out /*device [M, N], row stride ldo*/, int64_t ldo,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
  * Attention encoder.  Replace what dgl GATConv.forward runs on the graph
  * (reference call sites: GAT in staticGraphEncoder.py:170,174,190):
  * apply_edges(u_add_v('el','er')), LeakyReLU(negative_slope), edge_softmax

@@ -1,0 +1,217 @@
+// Y = act(X W^T + b) for a tall X [M, K] and a small weight [N, K]: the dense projection of
+// GraphConv / SGConv / SAGEConv (`torch.matmul(feat, weight)` inside dgl GraphConv.forward,
+// call sites spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:113,116) and
+// of the decoders' Linear layers (spiro/dtdg/models/decoder/torch/simpleDecoder.py:43-46).
+//
+// fp32 in, fp32 out, on the fp16 matrix cores with the three-plane operand format of
+// cell_split.hip (p0 = fp16(v), p1 = fp16(v/64), p2 = fp16((v - p0)*64); x*w = p0*p0 + p1*p2 +
+// p2*p1, fp32 accumulation): sums land closer to float64 than an fp32 FMA chain, operands
+// must lie within +-65504 (a larger one turns its output row into inf/NaN).
+//
+// The shape makes this an HBM-bound kernel (M*(K+N)*4 bytes against 3*2*M*K*N flops on
+// matrix cores that are ~15x faster than that), so the design is about the stream of X:
+//  * the weight planes ([K/16][3][N][16] fp16, from spmi_split_f16x3) sit in LDS for the
+//    lifetime of a workgroup (96 KB at K = N = 128) and are read as ds_read_b128 fragments;
+//  * X never touches LDS: the A fragment of v_mfma_f32_32x32x16_f16 is eight consecutive k
+//    of one row per lane, i.e. two float4 loads straight from global memory, split into the
+//    three planes in registers;
+//  * a wave owns 32 rows x all N columns and keeps the whole K of its rows in registers
+//    (K/2 VGPRs); as soon as the slice of K-step t is split, the same registers receive the
+//    K-step t of the wave's next tile, so 16 KB per wave (128 KB per CU) are in flight while
+//    the matrix cores work;
+//  * waves are independent after the weight load: no barrier in the loop.
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+
+struct RowsArgs {
+  const float* x;
+  int64_t ldx;
+  int64_t M;
+  const uint4* wp;  // weight planes, [KT][3][N][16] fp16
+  const float* bias;
+  int act;          // 0 none, 1 relu, 2 leaky_relu
+  float slope;
+  float* out;
+  int64_t ldo;
+};
+
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, f16x8& p0, f16x8& p1,
+                                       f16x8& p2) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const _Float16 h = static_cast<_Float16>(v[q]);
+    p0[q] = h;
+    p1[q] = static_cast<_Float16>(v[q] * 0x1p-6f);
+    p2[q] = static_cast<_Float16>((v[q] - static_cast<float>(h)) * 0x1p6f);
+  }
+}
+
+template <int KT, int NB>
+__global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
+  constexpr int N = NB * 32;
+  constexpr int PLANE = N * 32;           // bytes of one plane of one K-step
+  constexpr int KSTEP = 3 * PLANE;        // bytes of one K-step
+  constexpr int B16 = KT * KSTEP / 16;    // 16-byte chunks of the weight image
+  extern __shared__ uint4 smem4[];
+  const char* smem = reinterpret_cast<const char*>(smem4);
+
+  const int tid = threadIdx.x;
+  for (int c = tid; c < B16; c += 512) smem4[c] = p.wp[c];
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t n_tiles = (p.M + 31) / 32;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 8;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * 8 + wave;
+  if (tile >= n_tiles) return;
+
+  float bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bias[nb] = p.bias ? p.bias[nb * 32 + lr] : 0.0f;
+
+  // Rows past M are clamped to the last row: computed, never stored.
+  auto row_ptr = [&](int64_t t) {
+    int64_t r = t * 32 + lr;
+    r = r < p.M ? r : p.M - 1;
+    return p.x + r * p.ldx + 8 * lh;
+  };
+
+  float4 a[KT][2];
+  {
+    const float* src = row_ptr(tile);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
+      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+    }
+  }
+  const int b_rd = lr * 32 + lh * 16;
+
+  while (tile < n_tiles) {
+    const int64_t next = tile + stride;
+    // the last iteration re-reads its own tile: valid memory, nothing is done with it
+    const float* src = row_ptr(next < n_tiles ? next : tile);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      f16x8 p0, p1, p2;
+      split8(a[t][0], a[t][1], p0, p1, p2);
+      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
+      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+      // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
+      // the tile and then needs a second copy of the whole row in registers.
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sb = smem + t * KSTEP + b_rd;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32);
+        const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32 + PLANE);
+        const f16x8 b2 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32 + 2 * PLANE);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, b1, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b2, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b0, acc[nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // C layout of the 32x32 MFMA: element e of lane l is row (e&3) + 8 (e>>2) + 4 (l>>5),
+    // column l&31: a store covers two 128-byte row segments.
+    const int64_t row0 = tile * 32;
+    float* obase = p.out + row0 * p.ldo;  // wave-uniform
+    const int voff = 4 * lh * static_cast<int>(p.ldo) + lr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ur = (e & 3) + 8 * (e >> 2);
+      if (row0 + ur + 4 * lh >= p.M) continue;
+      float* o = obase + ur * p.ldo;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v = acc[nb][e] + bias[nb];
+        if (p.act == 1) v = fmaxf(v, 0.0f);
+        else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
+        o[voff + nb * 32] = v;
+      }
+    }
+    tile = next;
+  }
+}
+
+template <int KT, int NB>
+int launch(const RowsArgs& a, hipStream_t st) {
+  constexpr size_t lds = static_cast<size_t>(KT) * 3 * NB * 32 * 32;
+  static_assert(lds <= 160 * 1024, "weight image does not fit LDS");
+  auto kern = gemm_rows_kernel<KT, NB>;
+  static bool configured = false;
+  if (!configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const int64_t n_tiles = (a.M + 31) / 32;
+  const int64_t wgs = (n_tiles + 7) / 8;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int64_t cap = 256 * per_cu;
+  kern<<<static_cast<unsigned>(wgs < cap ? wgs : cap), 512, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("gemm_rows");
+  return SPMI_OK;
+}
+
+template <int KT>
+int launch_n(const RowsArgs& a, int64_t N, hipStream_t st) {
+  switch (N) {
+    case 32: return launch<KT, 1>(a, st);
+    case 64: return launch<KT, 2>(a, st);
+    case 96: return launch<KT, 3>(a, st);
+    default: return launch<KT, 4>(a, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmi_gemm_rows_supported(int64_t K, int64_t N) {
+  return (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 96 || N == 128);
+}
+
+int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void* w_planes, int64_t N,
+                   const float* bias, int act, float slope, float* out, int64_t ldo, void* stream) {
+  SPMI_REQUIRE(spmi_gemm_rows_supported(K, N), SPMI_ERR_UNSUPPORTED,
+               "spmi_gemm_rows: K must be 32, 64 or 128 and N 32, 64, 96 or 128 (K=%lld N=%lld)",
+               (long long)K, (long long)N);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: bad M=%lld",
+               (long long)M);
+  SPMI_REQUIRE(act >= 0 && act <= 2, SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: bad act %d", act);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(x && w_planes && out && ldx >= K && ldx % 4 == 0 && ldo >= N, SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_rows: null pointer or bad leading dimension");
+  SPMI_REQUIRE(ldx < (int64_t{1} << 24) && ldo < (int64_t{1} << 24), SPMI_ERR_UNSUPPORTED,
+               "spmi_gemm_rows: leading dimension too large");
+  SPMI_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
+                   (reinterpret_cast<uintptr_t>(w_planes) & 15u) == 0,
+               SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: x and w_planes must be 16-byte aligned");
+  RowsArgs a{};
+  a.x = x; a.ldx = ldx; a.M = M; a.wp = static_cast<const uint4*>(w_planes); a.bias = bias;
+  a.act = act; a.slope = slope; a.out = out; a.ldo = ldo;
+  hipStream_t st = spmi::as_stream(stream);
+  if (K == 32) return launch_n<2>(a, N, st);
+  if (K == 64) return launch_n<4>(a, N, st);
+  return launch_n<8>(a, N, st);
+}
+
+}  // extern "C"

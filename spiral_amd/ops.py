@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _native as nv
-from .graph import aggregate
+from .graph import _ACT_CODES, aggregate
 
 
 def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope: float,
@@ -110,6 +110,49 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Projections of a tall matrix by a small weight: "f16x3" = libspmi's memory-speed kernel on
+# the fp16 matrix cores (three-plane operands, fp32-chain accuracy, operands within +-65504),
+# "library" = torch.mm (hipBLASLt, fp32 matrix instruction).
+DENSE_GEMM = "f16x3"
+GEMM_ROWS_MIN_ROWS = 4096
+
+
+def _gemm_rows_ok(x: torch.Tensor, k: int, n: int) -> bool:
+    return (DENSE_GEMM == "f16x3" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] >= GEMM_ROWS_MIN_ROWS and x.shape[1] == k and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(nv.lib().spmi_gemm_rows_supported(k, n)))
+
+
+def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              act: Optional[str] = None, slope: float = 0.01) -> torch.Tensor:
+    """act(x @ weight_nk.T + bias) for x [rows, K] and weight_nk [N, K] in one launch of
+    spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`."""
+    n, k = weight_nk.shape
+    planes = split_f16x3(weight_nk)
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
+        nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), x.stride(0), x.shape[0], k, nv.ptr(planes), n,
+                                         nv.ptr(b), _ACT_CODES[act], float(slope), nv.ptr(out), n,
+                                         nv.stream()), "spmi_gemm_rows")
+    return out
+
+
+def _mm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ w (+ bias), w [K, N], no autograd."""
+    if _gemm_rows_ok(x, w.shape[0], w.shape[1]):
+        return gemm_rows(x, w.detach().t(), bias)
+    return torch.addmm(bias, x, w) if bias is not None else x @ w
+
+
+def _mm_nk(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x @ weight.T (+ bias), weight [N, K], no autograd."""
+    if _gemm_rows_ok(x, weight.shape[1], weight.shape[0]):
+        return gemm_rows(x, weight.detach(), bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 class _RowsTimesWeight(torch.autograd.Function):
     """y = x @ w (+ bias) for a tall x; the weight gradient x^T dy runs on gemm_tn."""
 
@@ -117,13 +160,13 @@ class _RowsTimesWeight(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return torch.addmm(bias, x, w) if bias is not None else x @ w
+        return _mm(x.detach(), w.detach(), None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = g.contiguous()
-        g_x = g @ w.t() if ctx.needs_input_grad[0] else None
+        g_x = _mm_nk(g, w) if ctx.needs_input_grad[0] else None
         g_w = gemm_tn(x, g) if ctx.needs_input_grad[1] else None
         g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return g_x, g_w, g_b
@@ -132,8 +175,11 @@ class _RowsTimesWeight(torch.autograd.Function):
 def rows_times_weight(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                       ) -> torch.Tensor:
     """x [rows, in] @ w [in, out] (+ bias), differentiable, tuned for rows >> in, out."""
-    if x.dim() != 2 or not (x.requires_grad or w.requires_grad) or not torch.is_grad_enabled():
+    if x.dim() != 2:
         return torch.addmm(bias, x, w) if bias is not None else x @ w
+    if not (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)) \
+            or not torch.is_grad_enabled():
+        return _mm(x.detach(), w.detach(), None if bias is None else bias.detach())
     return _RowsTimesWeight.apply(x, w, bias)
 
 
@@ -144,13 +190,13 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return _mm_nk(x.detach(), weight.detach(), None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        g_x = g @ weight if ctx.needs_input_grad[0] else None
+        g_x = _mm(g, weight) if ctx.needs_input_grad[0] else None
         g_w = gemm_tn(g, x) if ctx.needs_input_grad[1] else None
         g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return g_x, g_w, g_b
@@ -159,8 +205,11 @@ class _Linear(torch.autograd.Function):
 def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None
                 ) -> torch.Tensor:
     """F.linear(x, weight, bias) for x [rows, in] with rows >> in, out (differentiable)."""
-    if x.dim() != 2 or not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad):
+    if x.dim() != 2:
         return torch.nn.functional.linear(x, weight, bias)
+    if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad
+                                           or (bias is not None and bias.requires_grad)):
+        return _mm_nk(x.detach(), weight.detach(), None if bias is None else bias.detach())
     return _Linear.apply(x, weight, bias)
 
 

@@ -1,0 +1,98 @@
+"""The memory-speed projection kernel (spmi_gemm_rows) against float64 on the CPU: every
+supported (K, N), ragged row counts, strided input, bias and activations, gradients of the
+layers that use it, and the loud failure beyond fp16's range."""
+import numpy as np
+import pytest
+import torch
+
+from spiral_amd import _native as nv
+from spiral_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w_nk, bias, act, slope=0.01):
+    y = x.double().cpu() @ w_nk.double().cpu().t()
+    if bias is not None:
+        y = y + bias.double().cpu()
+    if act == "relu":
+        y = y.clamp(min=0)
+    elif act == "leaky_relu":
+        y = torch.where(y > 0, y, y * slope)
+    return y
+
+
+@pytest.mark.parametrize("k", [32, 64, 128])
+@pytest.mark.parametrize("n", [32, 64, 96, 128])
+def test_all_shapes(dev, k, n):
+    gen = torch.Generator().manual_seed(k * 1000 + n)
+    for m in (1, 31, 32, 33, 4096 + 77):
+        x = (torch.randn(m, k, generator=gen) * 2).to(dev)
+        w = (torch.randn(n, k, generator=gen) * 0.2).to(dev)
+        b = torch.randn(n, generator=gen).to(dev)
+        got = ops.gemm_rows(x, w, b)
+        want = _ref(x, w, b, None)
+        scale = float(want.abs().max())
+        assert float((got.double().cpu() - want).abs().max()) < 2e-6 * scale, (m, k, n)
+
+
+def test_closer_to_float64_than_the_library(dev):
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(200_000, 128, generator=gen) * 2).to(dev)
+    w = (torch.randn(128, 128, generator=gen) * 0.2).to(dev)
+    want = _ref(x, w, None, None)
+    err_kernel = float((ops.gemm_rows(x, w).double().cpu() - want).abs().max())
+    err_lib = float(((x @ w.t()).double().cpu() - want).abs().max())
+    assert err_kernel <= err_lib * 1.5, (err_kernel, err_lib)
+
+
+@pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
+def test_strided_input_bias_and_activation(dev, act):
+    gen = torch.Generator().manual_seed(11)
+    wide = torch.randn(5000, 200, generator=gen).to(dev)
+    x = wide[:, 8:136]                                   # row stride 200, 16-byte aligned start
+    w = (torch.randn(64, 128, generator=gen) * 0.1).to(dev)
+    b = torch.randn(64, generator=gen).to(dev)
+    assert ops._gemm_rows_ok(x, 128, 64)
+    got = ops.gemm_rows(x, w, b, act, 0.2)
+    want = _ref(x, w, b, act, 0.2)
+    assert float((got.double().cpu() - want).abs().max()) < 1e-5
+    assert not ops._gemm_rows_ok(wide[:, 3:131], 128, 64)  # misaligned start: library path
+
+
+def test_layers_route_through_it_and_gradients_match(dev):
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(6000, 128, generator=gen).to(dev).requires_grad_()
+    w = (torch.randn(128, 64, generator=gen) * 0.1).to(dev).requires_grad_()
+    b = torch.randn(64, generator=gen).to(dev).requires_grad_()
+    calls = []
+    real = ops.gemm_rows
+    ops.gemm_rows = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y = ops.rows_times_weight(x, w, b)
+        y.square().sum().backward()
+        lin_w = (torch.randn(32, 128, generator=gen) * 0.1).to(dev).requires_grad_()
+        z = ops.linear_rows(x.detach().requires_grad_(), lin_w, None)
+        z.sum().backward()
+    finally:
+        ops.gemm_rows = real
+    assert len(calls) == 4                                # two forwards, two input gradients
+    xd, wd, bd = (t.detach().double().cpu().requires_grad_() for t in (x, w, b))
+    (xd @ wd + bd).square().sum().backward()
+    for got, want in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        scale = float(want.abs().max())
+        assert float((got.double().cpu() - want).abs().max()) < 1e-5 * scale
+
+
+def test_out_of_range_operand_is_loud_and_bad_shapes_are_refused(dev):
+    x = torch.ones(4096, 32, device=dev)
+    x[100, 5] = 7.0e4
+    w = torch.full((32, 32), 0.01, device=dev)
+    out = ops.gemm_rows(x, w)
+    assert not torch.isfinite(out[100]).any()
+    assert torch.isfinite(out[:100]).all() and torch.isfinite(out[101:]).all()
+    assert not nv.lib().spmi_gemm_rows_supported(48, 32)
+    assert not nv.lib().spmi_gemm_rows_supported(128, 256)
+    with pytest.raises(nv.SpmiError):
+        nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), 32, 4096, 48, nv.ptr(w), 32, None, 0, 0.0,
+                                         nv.ptr(out), 32, nv.stream()), "spmi_gemm_rows")
