@@ -8,7 +8,10 @@
 // HBM; here the [N, I] input is read once and only the [N, out] result is written.
 // HBM-bound: N * (I + out) * 4 bytes.
 //
-// Mapping: a wave owns 64 rows, one per lane.  The input arrives in 32-column chunks
+// Two kernels.  Up to I = 256 the whole head runs on the fp16 matrix cores
+// (mlp_head_mfma_kernel, below); wider inputs take the all-VALU kernel described next.
+//
+// Mapping (VALU kernel): a wave owns 64 rows, one per lane.  The input arrives in 32-column chunks
 // (coalesced 128-byte row segments, the next chunk in flight while the current one is
 // consumed) and is transposed through a padded, wave-private LDS tile so that lane r reads
 // column k of row r conflict-free.  All weights sit in LDS (copied once per workgroup) and
@@ -37,6 +40,7 @@ struct MlpArgs {
   const float* w1t;   // [I][O1P], zero-padded columns
   const float* b1;    // [O1P]
   int out1;           // real width of layer 1
+  int o1p;            // padded width of layer 1 (8, 16 or 32): row length of w1t, length of b1
   int relu1;
   int n_rest;
   const float* rest;  // per layer: weight [out][in], then bias [out]
@@ -179,6 +183,216 @@ __global__ __launch_bounds__(64 * kWaves) void mlp_head_kernel(MlpArgs p) {
   }
 }
 
+// ---- the whole head on the matrix cores ---------------------------------------------------
+// Y1^T = W1 X^T with W1 as the A operand and the rows of x as the B operand of
+// v_mfma_f32_32x32x16_f16: lane (n, h) of a wave supplies eight consecutive k of data row n,
+// which is two float4 loads straight from global memory (no transpose through LDS), and
+// receives 16 of the 32 (zero-padded) layer-1 outputs of that same row:
+//     element e of lane (n, h)  =  unit (e & 3) + 8 (e >> 2) + 4 h  of row n.
+// Every later layer is again W_l (A operand, <= 32 x 32, zero-padded) times the activations
+// (B operand).  The contraction index of a matrix instruction can be numbered freely as long
+// as both operands agree, so W_l's image is stored with its k slots in the order in which a
+// lane already holds its activations (K-step t, slot 8 h + j  <->  element e = 8 t + j):
+// the accumulator of one layer is the B operand of the next with no data movement at all.
+// Operands travel as three fp16 planes (p0 = fp16(v), p1 = fp16(v/64), p2 = fp16((v - p0)*64);
+// x*w = p0*p0 + p1*p2 + p2*p1), which keeps the sums as close to float64 as an fp32 FMA
+// chain; inputs and activations must lie within +-65504.  A wave keeps the whole K of its 32
+// rows in registers and refills each K-step's registers with the next tile's as soon as they
+// are split, so its loads are in flight across the whole tail.
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+constexpr int kMfmaWaves = 4;
+constexpr int kPlane = 32 * 32;          // bytes: 32 units x 16 k slots (fp16)
+constexpr int kKStep = 3 * kPlane;       // three planes
+constexpr int kTailImage = 2 * kKStep;   // a later layer: two K-steps (32 inputs)
+
+__device__ __forceinline__ void split_planes(float v, _Float16& p0, _Float16& p1, _Float16& p2) {
+  p0 = static_cast<_Float16>(v);
+  p1 = static_cast<_Float16>(v * 0x1p-6f);
+  p2 = static_cast<_Float16>((v - static_cast<float>(p0)) * 0x1p6f);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& x0, f16x8& x1, f16x8& x2) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    _Float16 q0, q1, q2;
+    split_planes(v[q], q0, q1, q2);
+    x0[q] = q0;
+    x1[q] = q1;
+    x2[q] = q2;
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma3(const char* img, const f16x8& x0, const f16x8& x1,
+                                        const f16x8& x2, f32x16 acc) {
+  const f16x8 w0 = *reinterpret_cast<const f16x8*>(img);
+  const f16x8 w1 = *reinterpret_cast<const f16x8*>(img + kPlane);
+  const f16x8 w2 = *reinterpret_cast<const f16x8*>(img + 2 * kPlane);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, x0, acc, 0, 0, 0);
+}
+
+template <int KT>
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpArgs p) {
+  extern __shared__ float4 smem4[];
+  char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT][3][32][16] fp16
+  char* s_tail = s_l1 + KT * kKStep;                       // [n_rest][2][3][32][16] fp16
+  float* s_bias = reinterpret_cast<float*>(s_tail + p.n_rest * kTailImage);  // [n_rest][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+
+  // W1 (given [I][o1p], zero-padded columns) -> planes in the A layout, once per workgroup
+  for (int idx = tid; idx < KT * 16 * 32; idx += 64 * kMfmaWaves) {
+    const int k = idx >> 5, f = idx & 31;
+    const float v = f < p.o1p ? p.w1t[k * p.o1p + f] : 0.0f;
+    _Float16 q0, q1, q2;
+    split_planes(v, q0, q1, q2);
+    _Float16* dst = reinterpret_cast<_Float16*>(s_l1 + (k >> 4) * kKStep + f * 32) + (k & 15);
+    dst[0] = q0;
+    dst[kPlane / 2] = q1;
+    dst[kPlane] = q2;
+  }
+  // later layers (given [out][in] then bias [out], fp32): slot kappa of K-step t holds input
+  // unit (kappa & 3) + 8 (2 t + ((kappa & 7) >> 2)) + 4 (kappa >> 3)
+  {
+    const float* w = p.rest;
+    for (int l = 0; l < p.n_rest; ++l) {
+      const int in_w = p.in_w[l], out_w = p.out_w[l];
+      for (int idx = tid; idx < 2 * 32 * 16; idx += 64 * kMfmaWaves) {
+        const int t = idx >> 9, f = (idx >> 4) & 31, kappa = idx & 15;
+        const int unit = (kappa & 3) + 8 * (2 * t + ((kappa & 7) >> 2)) + 4 * (kappa >> 3);
+        const float v = (f < out_w && unit < in_w) ? w[f * in_w + unit] : 0.0f;
+        _Float16 q0, q1, q2;
+        split_planes(v, q0, q1, q2);
+        _Float16* dst =
+            reinterpret_cast<_Float16*>(s_tail + l * kTailImage + t * kKStep + f * 32) + kappa;
+        dst[0] = q0;
+        dst[kPlane / 2] = q1;
+        dst[kPlane] = q2;
+      }
+      if (tid < 32) s_bias[l * 32 + tid] = tid < out_w ? w[in_w * out_w + tid] : 0.0f;
+      w += (in_w + 1) * out_w;
+    }
+  }
+  __syncthreads();
+
+  const int64_t n_tiles = (p.M + 31) / 32;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kMfmaWaves;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * kMfmaWaves + wave;
+  if (tile >= n_tiles) return;  // no barrier below
+
+  float b1[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int f = (e & 3) + 8 * (e >> 2) + 4 * lh;
+    b1[e] = f < p.o1p ? p.b1[f] : 0.0f;
+  }
+  const int out_last = p.n_rest ? p.out_w[p.n_rest - 1] : p.out1;
+
+  float4 a[KT][2];
+  {
+    int64_t r = tile * 32 + lr;
+    r = r < p.M ? r : p.M - 1;  // clamp: computed, never stored
+    const float* src = p.x + r * p.ldx + 8 * lh;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
+      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+    }
+  }
+  const int frag = lr * 32 + lh * 16;  // this lane's 16 bytes inside a plane
+
+  while (tile < n_tiles) {
+    const int64_t next = tile + stride;
+    int64_t r = (next < n_tiles ? next : tile) * 32 + lr;  // last pass re-reads its own tile
+    r = r < p.M ? r : p.M - 1;
+    const float* src = p.x + r * p.ldx + 8 * lh;
+
+    f32x16 cur;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cur[e] = b1[e];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const float v[8] = {a[t][0].x, a[t][0].y, a[t][0].z, a[t][0].w,
+                          a[t][1].x, a[t][1].y, a[t][1].z, a[t][1].w};
+      f16x8 x0, x1, x2;
+      split8(v, x0, x1, x2);
+      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
+      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+      __builtin_amdgcn_sched_barrier(0);  // keeps the reloads from being hoisted over the tile
+      cur = mfma3(s_l1 + t * kKStep + frag, x0, x1, x2, cur);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.relu1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cur[e] = fmaxf(cur[e], 0.0f);
+    }
+
+    for (int l = 0; l < p.n_rest; ++l) {
+      const char* img = s_tail + l * kTailImage + frag;
+      f32x16 nxt;
+      {  // bias of units 8 q + 4 lh + {0..3} = elements 4 q .. 4 q + 3
+        const float* bl = s_bias + l * 32 + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bq = *reinterpret_cast<const float4*>(bl + 8 * q);
+          nxt[4 * q + 0] = bq.x;
+          nxt[4 * q + 1] = bq.y;
+          nxt[4 * q + 2] = bq.z;
+          nxt[4 * q + 3] = bq.w;
+        }
+      }
+      f16x8 x0, x1, x2;
+      {
+        const float v[8] = {cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]};
+        split8(v, x0, x1, x2);
+        nxt = mfma3(img, x0, x1, x2, nxt);
+      }
+      if (p.in_w[l] > 16) {  // uniform
+        const float v[8] = {cur[8], cur[9], cur[10], cur[11], cur[12], cur[13], cur[14], cur[15]};
+        split8(v, x0, x1, x2);
+        nxt = mfma3(img + kKStep, x0, x1, x2, nxt);
+      }
+      if (p.relu[l]) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) nxt[e] = fmaxf(nxt[e], 0.0f);
+      }
+      cur = nxt;
+    }
+
+    const int64_t row = tile * 32 + lr;
+    if (row < p.M) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int f = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (f < out_last) p.out[row * p.ldo + f] = final_activation(cur[e], p.final_act);
+      }
+    }
+    tile = next;
+  }
+}
+
+template <int KT>
+int launch_mfma(const MlpArgs& a, hipStream_t st) {
+  auto kernel = mlp_head_mfma_kernel<KT>;
+  const size_t lds = static_cast<size_t>(KT) * kKStep + static_cast<size_t>(a.n_rest) * (kTailImage + 128);
+  static size_t configured = 0;
+  if (lds > configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  const int64_t n_tiles = (a.M + 31) / 32;
+  const int64_t wgs = (n_tiles + kMfmaWaves - 1) / kMfmaWaves;
+  kernel<<<static_cast<unsigned>(wgs < 512 ? wgs : 512), 64 * kMfmaWaves, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("mlp_head_mfma");
+  return SPMI_OK;
+}
+
 size_t lds_bytes(int64_t I, int o1p, int rest_floats) {
   return sizeof(float) * (static_cast<size_t>(I) * o1p + ((rest_floats + 3) & ~3) +
                           static_cast<size_t>(kWaves) * kWaveFloats);
@@ -247,7 +461,19 @@ int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const f
   SPMI_REQUIRE(ldo >= width, SPMI_ERR_INVALID_ARG, "spmi_mlp_head_fwd: ldo %lld < output width %d",
                (long long)ldo, width);
   a.final_act = final_act; a.out = out; a.ldo = ldo;
+  a.o1p = out1 <= 8 ? 8 : (out1 <= 16 ? 16 : 32);
   hipStream_t st = spmi::as_stream(stream);
+  switch (I) {  // up to 256 inputs a wave holds its rows in registers: the matrix-core kernel
+    case 32: return launch_mfma<2>(a, st);
+    case 64: return launch_mfma<4>(a, st);
+    case 96: return launch_mfma<6>(a, st);
+    case 128: return launch_mfma<8>(a, st);
+    case 160: return launch_mfma<10>(a, st);
+    case 192: return launch_mfma<12>(a, st);
+    case 224: return launch_mfma<14>(a, st);
+    case 256: return launch_mfma<16>(a, st);
+    default: break;
+  }
   if (out1 <= 8) return launch<8>(a, st);
   if (out1 <= 16) return launch<16>(a, st);
   return launch<32>(a, st);

@@ -37,6 +37,10 @@ def _randomise(mlp, seed):
     (10_000, 256, [], 7, "tanh"),                  # a single Linear
     (6000, 64, [8, 8, 8, 8, 8, 8, 8], 2, "relu"),  # eight layers
     (70_000, 128, [17, 31], 32, "linear"),
+    (5001, 96, [10, 20], 1, "linear"),
+    (4100, 160, [32, 5], 4, "sigmoid"),
+    (4500, 512, [10, 20], 1, "linear"),            # more than 256 inputs: the all-VALU kernel
+    (4200, 320, [16], 2, "tanh"),
 ])
 def test_fused_head_equals_layerwise(dev, n, i, dims, out, act):
     torch.manual_seed(n % 97)
