@@ -254,8 +254,8 @@ int spmi_cell_fused_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * weights, in-kernel for x and the state) and each product is summed from the six piece
  * products above 2^-24; pre-activations agree with an fp32 FMA chain to a few fp32
  * roundings.  ws_ih / ws_hh: weight_ih [G*H, I] / weight_hh [G*H, H] (torch's own
- * layout) passed through spmi_split_bf16x3, which writes [cols/16][3][rows][16] bfloat16
- * (3 * rows * cols elements).  Other arguments as spmi_cell_fused_fwd, same shape limits. */
+ * layout) passed through spmi_split_bf16x3, which writes [cols/16][3][2][rows][8] bfloat16
+ * (K-step, piece, half of the K-step, row, k; 3 * rows * cols elements).  Other arguments as spmi_cell_fused_fwd, same shape limits. */
 int spmi_split_bf16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
                       void* out /*device bf16, 3*rows*cols*/, void* stream);
 int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
@@ -271,7 +271,7 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * fp32 FMA chain.  Domain: |v| <= 65504 for x, the state and the weights; a larger operand
  * turns into infinity and its output row into inf/NaN (spmi_cell_split_fwd has no such
  * limit).  ws_ih / ws_hh come from spmi_split_f16x3 (same tiling as spmi_split_bf16x3:
- * [cols/16][3][rows][16] 16-bit words).  Arguments and shape limits as
+ * [cols/16][3][2][rows][8] 16-bit words).  Arguments and shape limits as
  * spmi_cell_split_fwd. */
 int spmi_split_f16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
                        void* out /*device 16-bit words, 3*rows*cols*/, void* stream);

@@ -30,10 +30,10 @@
 // Mapping (as in cell_fused.hip): a workgroup owns 128 batch rows and all hidden units of
 // them; waves form a 4 x WC grid of 32-row groups x column groups, JSUB 32-unit column
 // blocks x NACC accumulator sets per wave.  K runs in steps of 16 through a double-buffered
-// LDS stage.  Weights arrive pre-split and pre-tiled ([K/16][3][G*H][16] bf16: the B image
+// LDS stage.  Weights arrive pre-split and pre-tiled ([K/16][3][2][G*H][8] 16-bit words: the B image
 // of a K-step is one contiguous block); x and state rows are split while they are staged.
-// Both operand images are [piece][row or n][16 k] with 32-byte rows: a wave's
-// ds_read_b128 of a fragment covers 2 KB contiguously (conflict-free), one read per piece.
+// Both operand images are [plane][k half][row or n][8 k]: the 32 lanes of a half read 512
+// contiguous bytes with one ds_read_b128 (conflict-free), one read per plane.
 
 #include <type_traits>
 
@@ -115,9 +115,12 @@ __device__ __forceinline__ void split_f16x3(float v, _Float16& p0, _Float16& p1,
   p2 = static_cast<_Float16>((v - static_cast<float>(p0)) * 0x1p6f);
 }
 
-// Weights [rows][cols] fp32 -> [cols/16][3 pieces][rows][16] bf16: for one K-step the three
-// piece images of all rows are one contiguous block in the order the LDS stage wants them,
-// so the staging loads are fully coalesced.
+// Weights [rows][cols] fp32 -> [cols/16][3 planes][2 k halves][rows][8] 16-bit words: for one
+// K-step the plane images of all rows are one contiguous block in the order the LDS stage
+// wants them, so the staging loads are fully coalesced.  A fragment read (lane (row, half)
+// takes 16 bytes) then covers 512 contiguous bytes per half, which ds_read_b128 serves
+// without bank conflicts; rows of 16 k (32 bytes, lanes 32 bytes apart) cost two-way
+// conflicts on every read (SQ_LDS_BANK_CONFLICT was 38 % of the LDS-array cycles).
 template <int MODE>
 __global__ void split_weights_kernel(const float* __restrict__ w, int64_t rows, int64_t cols,
                                      uint16_t* __restrict__ out) {
@@ -138,7 +141,7 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int64_t rows, 
     q1 = __builtin_bit_cast(uint16_t, mid);
     q2 = __builtin_bit_cast(uint16_t, lo);
   }
-  const int64_t base = (k / 16) * 3 * rows * 16 + n * 16 + (k % 16);
+  const int64_t base = (k / 16) * 3 * rows * 16 + ((k % 16) / 8) * rows * 8 + n * 8 + (k % 8);
   out[base] = q0;
   out[base + rows * 16] = q1;
   out[base + 2 * rows * 16] = q2;
@@ -231,7 +234,7 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     if (PREFETCH && i + 1 < NB) {
-      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * ROWB;
+      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * 16;
 #pragma unroll
       for (int q = 0; q < 3; ++q) b_nxt[q] = *reinterpret_cast<const bf16x8*>(sb + off + q * B_PLANE);
     }
@@ -261,14 +264,104 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
 #pragma unroll
       for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];
     } else if (i + 1 < NB) {
-      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * ROWB;
+      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * 16;
 #pragma unroll
       for (int q = 0; q < 3; ++q) b_cur[q] = *reinterpret_cast<const bf16x8*>(sb + off + q * B_PLANE);
     }
   }
 }
 
-template <int MODE, int CELL, int JSUB, int WC, bool IDS>
+// One slice of the staging work of a K-step: slices 0 .. 5 APT - 1 split the x/state rows
+// (two elements per slice) and store their three planes, the rest store the weight chunks.
+// `k` is a constant after unrolling.  The last, partly filled weight chunk is stored
+// unconditionally (threads past the tile write a dump row behind the stages).
+template <int APT, int BPT, int B16, int THREADS, int A_PLANE, int A_BYTES>
+__device__ __forceinline__ void stage_slice(int k, const StageRegs<APT, BPT>& r, f16x4 (&p0)[APT],
+                                            f16x4 (&p1)[APT], f16x4 (&p2)[APT], char* stage,
+                                            char* dump, const int (&a_dst)[APT], int tid) {
+  if (k < 5 * APT) {
+    const int i = k / 5, part = k % 5;
+    if (part < 2) {
+      const float v0 = part == 0 ? r.a[i].x : r.a[i].z;
+      const float v1 = part == 0 ? r.a[i].y : r.a[i].w;
+      _Float16 h, m, l;
+      split_f16x3(v0, h, m, l);
+      p0[i][2 * part] = h;
+      p1[i][2 * part] = m;
+      p2[i][2 * part] = l;
+      split_f16x3(v1, h, m, l);
+      p0[i][2 * part + 1] = h;
+      p1[i][2 * part + 1] = m;
+      p2[i][2 * part + 1] = l;
+    } else if (part == 2) {
+      *reinterpret_cast<f16x4*>(stage + a_dst[i]) = p0[i];
+    } else if (part == 3) {
+      *reinterpret_cast<f16x4*>(stage + A_PLANE + a_dst[i]) = p1[i];
+    } else {
+      *reinterpret_cast<f16x4*>(stage + 2 * A_PLANE + a_dst[i]) = p2[i];
+    }
+  } else {
+    const int i = k - 5 * APT;
+    const int c = tid + i * THREADS;
+    char* dst = ((i + 1) * THREADS <= B16 || c < B16) ? stage + A_BYTES + c * 16 : dump;
+    *reinterpret_cast<uint4*>(dst) = r.b[i];
+  }
+}
+
+// One K-step of the pipelined loop (f16x3 only): the matrix instructions of step t with the
+// staging of step t+1 placed BETWEEN them.  Waves issue in order, so staging overlaps matrix
+// work only where the program order says so; the slices start after the first few MFMAs
+// because the global loads of step t+1 were issued one step earlier and need that long.
+// A fence after every 32-column block keeps the compiler from regrouping the sequence.
+template <int CELL, int JSUB, int JC, int A_PLANE, int B_PLANE, bool HPHASE, int APT, int BPT,
+          int B16, int THREADS, int A_BYTES>
+__device__ __forceinline__ void piped_step(f32x16 (&acc)[JSUB][Cell<CELL>::NACC], const char* sa,
+                                           const char* sb, const StageRegs<APT, BPT>& r,
+                                           char* stage, char* dump, const int (&a_dst)[APT],
+                                           int tid) {
+  using C = Cell<CELL>;
+  constexpr int NB = C::NG * JSUB;
+  constexpr int ROWB = kBK * 2;
+  constexpr int SLOTS = 3 * NB;
+  constexpr int SLICES = 5 * APT + BPT;
+  constexpr int LEAD = SLOTS - SLICES < 0 ? 0 : (SLOTS - SLICES < 5 ? SLOTS - SLICES : 5);
+  constexpr int LATE = SLOTS - LEAD;  // slots that carry staging work
+  const f16x8 a0 = *reinterpret_cast<const f16x8*>(sa);
+  const f16x8 a1 = *reinterpret_cast<const f16x8*>(sa + A_PLANE);
+  const f16x8 a2 = *reinterpret_cast<const f16x8*>(sa + 2 * A_PLANE);
+  f16x8 b_cur[3], b_nxt[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b_cur[q] = *reinterpret_cast<const f16x8*>(sb + q * B_PLANE);
+  f16x4 p0[APT], p1[APT], p2[APT];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (i + 1 < NB) {
+      const int off = (((i + 1) / JSUB) * JC + ((i + 1) % JSUB) * 32) * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b_nxt[q] = *reinterpret_cast<const f16x8*>(sb + off + q * B_PLANE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int g = i / JSUB, sub = i % JSUB;
+    const int ai = HPHASE ? C::acc_h[g] : C::acc_x[g];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const f16x8& fa = m == 0 ? a2 : (m == 1 ? a1 : a0);
+      const f16x8& fb = m == 0 ? b_cur[1] : (m == 1 ? b_cur[2] : b_cur[0]);
+      acc[sub][ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[sub][ai], 0, 0, 0);
+      const int slot = 3 * i + m - LEAD;
+      if (slot >= 0) {
+#pragma unroll
+        for (int k = slot * SLICES / LATE; k < (slot + 1) * SLICES / LATE; ++k)
+          stage_slice<APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(k, r, p0, p1, p2, stage, dump, a_dst, tid);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];
+  }
+}
+
+template <int MODE, int CELL, int JSUB, int WC, bool IDS, bool PIPE = false>
 __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel(SplitArgs p) {
   using C = Cell<CELL>;
   constexpr int THREADS = 256 * WC;
@@ -312,27 +405,27 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
     const int idx = tid + i * THREADS;
     const int c4 = (idx & 3) * 4;
     int trow = idx >> 2;
-    a_dst[i] = trow * ROWB + c4 * 2;
+    a_dst[i] = ((c4 >> 3) * kRows + trow) * 16 + (c4 & 7) * 2;
     if (row0 + trow >= p.M) trow = static_cast<int>(p.M - 1 - row0);  // clamp: computed, not stored
     ax[i] = trow * static_cast<int>(p.ldx) + c4;
     if constexpr (IDS) ah[i] = p.ids[row0 + trow] * H + c4;
     else ah[i] = trow * H + c4;
   }
 
-  const int a_rd = (rg * 32 + lr) * ROWB + lh * 16;
-  const int b_rd = A_BYTES + (cg * JW + lr) * ROWB + lh * 16;
+  const int a_rd = (lh * kRows + rg * 32 + lr) * 16;
+  const int b_rd = A_BYTES + (lh * NC + cg * JW + lr) * 16;
 
   for (int j0 = 0; j0 < H; j0 += JC) {
-    // B staging: chunk c -> piece c / (2 NC), tile row (c % (2 NC)) / 2, half (c & 1).  The
-    // weights are stored [K/16][piece][n][16], so a K-step advances every offset by 3*GH*16.
+    // B staging: chunk c -> (plane, k half) c / NC, tile row c % NC.  The weights are stored
+    // [K/16][plane][k half][n][8], so a K-step advances every offset by 3*GH*16.
     int boff[BPT];
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int c = tid + i * THREADS;
-      const int piece = c / (2 * NC);
-      const int nl = (c % (2 * NC)) >> 1;
-      const int brow = (c < B16) ? piece * GH + (nl / JC) * H + j0 + (nl % JC) : 0;
-      boff[i] = brow * 16 + (c & 1) * 8;
+      const int ph = c / NC;  // plane * 2 + k half
+      const int nl = c % NC;
+      const int brow = (c < B16) ? ph * GH + (nl / JC) * H + j0 + (nl % JC) : 0;
+      boff[i] = brow * 8;
     }
     const int bstep = 3 * GH;  // 16-element rows per K-step
 
@@ -348,6 +441,41 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
 
     const int tiles_x = p.I / kBK;
     const int tiles_h = H / kBK;
+    if constexpr (PIPE) {
+      static_assert(MODE == MODE_F16X3, "the pipelined loop is written for the fp16 planes");
+      const int total = tiles_x + tiles_h;
+      char* dump = smem + 2 * STAGE + (tid & 63) * 16;
+      __syncthreads();  // the previous pass has finished reading both buffers
+      load_stage<APT, BPT>(regs, xbase, ax, 0, p.ws_ih, boff, 0);
+      store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
+      if (1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, kBK, p.ws_ih, boff, bstep);
+      else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
+      __syncthreads();
+      int buf = 0;
+      // two loops, one per phase: a single loop that picks the accumulator set by a branch
+      // makes the compiler keep a second copy of all accumulators
+      for (int s = 0; s < tiles_x; ++s) {
+        const char* cur = smem + buf * STAGE;
+        piped_step<CELL, JSUB, JC, A_PLANE, B_PLANE, false, APT, BPT, B16, THREADS, A_BYTES>(
+            acc, cur + a_rd, cur + b_rd, regs, smem + (buf ^ 1) * STAGE, dump, a_dst, tid);
+        const int s2 = s + 2;  // the registers are free again: fetch the step after next
+        if (s2 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, s2 * kBK, p.ws_ih, boff, s2 * bstep);
+        else if (s2 < total)
+          load_stage<APT, BPT>(regs, hbase, ah, (s2 - tiles_x) * kBK, p.ws_hh, boff, (s2 - tiles_x) * bstep);
+        __syncthreads();
+        buf ^= 1;
+      }
+      for (int t = 0; t + 1 < tiles_h; ++t) {
+        const char* cur = smem + buf * STAGE;
+        piped_step<CELL, JSUB, JC, A_PLANE, B_PLANE, true, APT, BPT, B16, THREADS, A_BYTES>(
+            acc, cur + a_rd, cur + b_rd, regs, smem + (buf ^ 1) * STAGE, dump, a_dst, tid);
+        if (t + 2 < tiles_h) load_stage<APT, BPT>(regs, hbase, ah, (t + 2) * kBK, p.ws_hh, boff, (t + 2) * bstep);
+        __syncthreads();
+        buf ^= 1;
+      }
+      mfma_stage<MODE, CELL, JSUB, JC, A_PLANE, B_PLANE, true>(acc, smem + buf * STAGE + a_rd,
+                                                               smem + buf * STAGE + b_rd);
+    } else {
     __syncthreads();  // the previous pass has finished reading both buffers
     load_stage<APT, BPT>(regs, xbase, ax, 0, p.ws_ih, boff, 0);
     store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
@@ -373,6 +501,7 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
       buf ^= 1;
     }
 
+    }
     // ---- epilogue: gates, state update, stores (same accumulator layout as the fp32 kernel).
     // Row addresses are "uniform row base + lane offset", so that no per-element 64-bit
     // address is kept alive across the K loop.
@@ -473,10 +602,11 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
 template <int MODE, int CELL, int JSUB, int WC>
 int launch_config(const SplitArgs& a, hipStream_t st) {
   constexpr int NC = Cell<CELL>::NG * JSUB * 32 * WC;
-  constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2);
+  constexpr bool PIPE = MODE == MODE_F16X3 && JSUB == 2;  // staging between the MFMAs: 3-4 % faster
+  constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2) + (PIPE ? 1024 : 0);
   static_assert(lds <= 160 * 1024, "LDS stage does not fit");
-  auto plain = split_cell_kernel<MODE, CELL, JSUB, WC, false>;
-  auto gathered = split_cell_kernel<MODE, CELL, JSUB, WC, true>;
+  auto plain = split_cell_kernel<MODE, CELL, JSUB, WC, false, PIPE>;
+  auto gathered = split_cell_kernel<MODE, CELL, JSUB, WC, true, PIPE>;
   static bool configured = false;
   if (!configured) {
     SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plain),

@@ -10,7 +10,7 @@
 //
 // The shape makes this an HBM-bound kernel (M*(K+N)*4 bytes against 3*2*M*K*N flops on
 // matrix cores that are ~15x faster than that), so the design is about the stream of X:
-//  * the weight planes ([K/16][3][N][16] fp16, from spmi_split_f16x3) sit in LDS for the
+//  * the weight planes ([K/16][3][2][N][8] fp16, from spmi_split_f16x3) sit in LDS for the
 //    lifetime of a workgroup (96 KB at K = N = 128) and are read as ds_read_b128 fragments;
 //  * X never touches LDS: the A fragment of v_mfma_f32_32x32x16_f16 is eight consecutive k
 //    of one row per lane, i.e. two float4 loads straight from global memory, split into the
@@ -32,7 +32,7 @@ struct RowsArgs {
   const float* x;
   int64_t ldx;
   int64_t M;
-  const uint4* wp;  // weight planes, [KT][3][N][16] fp16
+  const uint4* wp;  // weight planes, [KT][3][2][N][8] fp16
   const float* bias;
   int act;          // 0 none, 1 relu, 2 leaky_relu
   float slope;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
       a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
     }
   }
-  const int b_rd = lr * 32 + lh * 16;
+  const int b_rd = (lh * N + lr) * 16;  // [plane][k half][n][8]: 512 contiguous bytes per half
 
   while (tile < n_tiles) {
     const int64_t next = tile + stride;
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
       const char* sb = smem + t * KSTEP + b_rd;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32);
-        const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32 + PLANE);
-        const f16x8 b2 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 32 + 2 * PLANE);
+        const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 16);
+        const f16x8 b1 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 16 + PLANE);
+        const f16x8 b2 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 16 + 2 * PLANE);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, b1, acc[nb], 0, 0, 0);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b2, acc[nb], 0, 0, 0);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b0, acc[nb], 0, 0, 0);

@@ -236,8 +236,8 @@ __device__ __forceinline__ f32x16 mfma3(const char* img, const f16x8& x0, const 
 template <int KT>
 __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpArgs p) {
   extern __shared__ float4 smem4[];
-  char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT][3][32][16] fp16
-  char* s_tail = s_l1 + KT * kKStep;                       // [n_rest][2][3][32][16] fp16
+  char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT][3][2][32][8] fp16
+  char* s_tail = s_l1 + KT * kKStep;                       // [n_rest][2][3][2][32][8] fp16
   float* s_bias = reinterpret_cast<float*>(s_tail + p.n_rest * kTailImage);  // [n_rest][32]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
     const float v = f < p.o1p ? p.w1t[k * p.o1p + f] : 0.0f;
     _Float16 q0, q1, q2;
     split_planes(v, q0, q1, q2);
-    _Float16* dst = reinterpret_cast<_Float16*>(s_l1 + (k >> 4) * kKStep + f * 32) + (k & 15);
+    _Float16* dst = reinterpret_cast<_Float16*>(s_l1 + (k >> 4) * kKStep + ((k >> 3) & 1) * 512 + f * 16) + (k & 7);
     dst[0] = q0;
     dst[kPlane / 2] = q1;
     dst[kPlane] = q2;
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
         const float v = (f < out_w && unit < in_w) ? w[f * in_w + unit] : 0.0f;
         _Float16 q0, q1, q2;
         split_planes(v, q0, q1, q2);
-        _Float16* dst =
-            reinterpret_cast<_Float16*>(s_tail + l * kTailImage + t * kKStep + f * 32) + kappa;
+        _Float16* dst = reinterpret_cast<_Float16*>(s_tail + l * kTailImage + t * kKStep +
+                                                    (kappa >> 3) * 512 + f * 16) + (kappa & 7);
         dst[0] = q0;
         dst[kPlane / 2] = q1;
         dst[kPlane] = q2;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
       a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
     }
   }
-  const int frag = lr * 32 + lh * 16;  // this lane's 16 bytes inside a plane
+  const int frag = lh * 512 + lr * 16;  // this lane's 16 bytes inside a plane [k half][unit][8]
 
   while (tile < n_tiles) {
     const int64_t next = tile + stride;

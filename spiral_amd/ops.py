@@ -445,10 +445,11 @@ CELL_GEMM = "f16x3"
 
 def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     """The weight matrix [rows, cols] as exact bf16 pieces (hi + mid + lo == w), tiled
-    [cols/16, 3, rows, 16] for the split-precision cell kernel."""
+    [cols/16, 3, 2, rows, 8] (K-step, piece, half of the K-step, row, k) for the
+    split-precision cell kernel."""
     w = w.detach().contiguous()
     rows, cols = w.shape
-    out = torch.empty(cols // 16, 3, rows, 16, dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(cols // 16, 3, 2, rows, 8, dtype=torch.bfloat16, device=w.device)
     with torch.cuda.device(w.device):
         nv.check(nv.lib().spmi_split_bf16x3(nv.ptr(w), rows, cols, nv.ptr(out), nv.stream()),
                  "spmi_split_bf16x3")
@@ -457,10 +458,11 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
 
 def split_f16x3(w: torch.Tensor) -> torch.Tensor:
     """The weight matrix [rows, cols] as the planes fp16(w), fp16(w/64), fp16((w - fp16(w))*64),
-    tiled [cols/16, 3, rows, 16] for the three-product cell kernel."""
+    tiled [cols/16, 3, 2, rows, 8] (K-step, plane, half of the K-step, row, k) for the
+    three-product kernels."""
     w = w.detach().contiguous()
     rows, cols = w.shape
-    out = torch.empty(cols // 16, 3, rows, 16, dtype=torch.float16, device=w.device)
+    out = torch.empty(cols // 16, 3, 2, rows, 8, dtype=torch.float16, device=w.device)
     with torch.cuda.device(w.device):
         nv.check(nv.lib().spmi_split_f16x3(nv.ptr(w), rows, cols, nv.ptr(out), nv.stream()),
                  "spmi_split_f16x3")

@@ -62,19 +62,19 @@ def test_gru_lstm_rnn_steps(dev, mode, m, i, h, gather):
 
 def test_split_pieces_are_exact(dev):
     w = torch.randn(96, 64, device=dev) * torch.logspace(-6, 3, 64, device=dev)
-    pieces = ops.split_bf16x3(w)                                    # [cols/16, 3, rows, 16]
-    assert pieces.shape == (4, 3, 96, 16) and pieces.dtype == torch.bfloat16
-    total = pieces.float().sum(1)                                   # [4, 96, 16]
-    back = total.permute(1, 0, 2).reshape(96, 64)
+    pieces = ops.split_bf16x3(w)                                    # [cols/16, 3, 2, rows, 8]
+    assert pieces.shape == (4, 3, 2, 96, 8) and pieces.dtype == torch.bfloat16
+    total = pieces.float().sum(1)                                   # [4, 2, 96, 8]
+    back = total.permute(2, 0, 1, 3).reshape(96, 64)
     assert torch.equal(back, w)
 
 
 def test_f16x3_planes(dev):
     """p0 + p2/64 reproduces w to ~2^-22 and p1 = w/64 to fp16 rounding, over fp16's range."""
     w = torch.randn(96, 64, device=dev) * torch.logspace(-3, 3, 64, device=dev)
-    planes = ops.split_f16x3(w)                                     # [cols/16, 3, rows, 16]
-    assert planes.shape == (4, 3, 96, 16) and planes.dtype == torch.float16
-    un = lambda p: p.double().permute(1, 0, 2).reshape(96, 64)
+    planes = ops.split_f16x3(w)                                     # [cols/16, 3, 2, rows, 8]
+    assert planes.shape == (4, 3, 2, 96, 8) and planes.dtype == torch.float16
+    un = lambda p: p.double().permute(2, 0, 1, 3).reshape(96, 64)
     p0, p1, p2 = un(planes[:, 0]), un(planes[:, 1]), un(planes[:, 2])
     wd = w.double()
     assert ((p0 + p2 / 64 - wd).abs() <= wd.abs() * 2.0 ** -21 + 2.0 ** -31).all()
