@@ -94,10 +94,13 @@ struct SplitArgs {
   float* saved;
 };
 
-__device__ __forceinline__ float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+// v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal: a full division sequence
+// of a dozen instructions, twice per state element.
+__device__ __forceinline__ float rcpf_(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float sigmoidf_(float v) { return rcpf_(1.0f + __expf(-v)); }
 __device__ __forceinline__ float tanhf_(float v) {
   const float e = __expf(2.0f * (v > 15.0f ? 15.0f : v));  // NaN stays NaN
-  return (e - 1.0f) * __frcp_rn(e + 1.0f);
+  return 1.0f - 2.0f * rcpf_(e + 1.0f);
 }
 
 // v = hi + mid + lo exactly (each difference of an fp32 and its bf16 rounding is exact).
@@ -361,6 +364,88 @@ __device__ __forceinline__ void piped_step(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
   }
 }
 
+// Gate math of one state element; `h` / `c` are the old state, the new one is returned.
+template <int CELL>
+__device__ __forceinline__ float gate_math(const float (&a)[Cell<CELL>::NACC], const float (&bi)[Cell<CELL>::NG],
+                                           const float (&bhh)[Cell<CELL>::NG], float h, float& c) {
+  if constexpr (CELL == CELL_GRU) {
+    // r and z from one reciprocal: with p = 1 + e^-a, q = 1 + e^-b and i = 1/(p q),
+    // r = q i and z = p i.  The exponents are clamped at 40 so that p q stays finite.
+    const float ar = a[0] + (bi[0] + bhh[0]);
+    const float az = a[1] + (bi[1] + bhh[1]);
+    // (a NaN pre-activation is dropped by fminf here and carried by the n gate below, whose
+    // clamp keeps it: x or h out of range makes a[2] or a[3] NaN along with a[0], a[1])
+    const float pr = 1.0f + __expf(fminf(-ar, 40.0f));
+    const float pz = 1.0f + __expf(fminf(-az, 40.0f));
+    const float inv = rcpf_(pr * pz);
+    const float r = pz * inv;
+    const float z = pr * inv;
+    const float n = tanhf_(a[2] + bi[2] + r * (a[3] + bhh[2]));
+    return n + z * (h - n);
+  } else if constexpr (CELL == CELL_LSTM) {
+    const float ig = sigmoidf_(a[0] + (bi[0] + bhh[0]));
+    const float fg = sigmoidf_(a[1] + (bi[1] + bhh[1]));
+    const float gg = tanhf_(a[2] + (bi[2] + bhh[2]));
+    const float og = sigmoidf_(a[3] + (bi[3] + bhh[3]));
+    c = fg * c + ig * gg;
+    return og * tanhf_(c);
+  } else {
+    return tanhf_(a[0] + (bi[0] + bhh[0]));
+  }
+}
+
+// Epilogue of a full tile whose state rows are contiguous and whose gate values nobody
+// wants back (inference): no per-element bounds test, the sixteen old-state values of a
+// 32-column block loaded before the math, every address a uniform row base plus one 32-bit
+// lane offset.
+template <int CELL, int JSUB, int JW>
+__device__ __forceinline__ void epilogue_full_tile(const SplitArgs& p,
+                                                   f32x16 (&acc)[JSUB][Cell<CELL>::NACC],
+                                                   int64_t urow0, int jbase, int lr, int lh,
+                                                   bool write_mem) {
+  using C = Cell<CELL>;
+  constexpr int NG = C::NG, NACC = C::NACC;
+  const int H = p.H;
+  const size_t rowb = static_cast<size_t>(H) * sizeof(float);
+#pragma unroll
+  for (int s = 0; s < JSUB; ++s) {
+    const int j = jbase + s * 32 + lr;
+    float bi[NG], bhh[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      bi[g] = p.b_ih ? p.b_ih[g * H + j] : 0.0f;
+      bhh[g] = p.b_hh ? p.b_hh[g * H + j] : 0.0f;
+    }
+    const uint32_t lane_off = static_cast<uint32_t>(4 * lh * H + j) * 4u;  // bytes
+    char* hm = reinterpret_cast<char*>(p.h_mem + urow0 * H);
+    char* ho = reinterpret_cast<char*>(p.h_out + urow0 * H);
+    char* cm = CELL == CELL_LSTM ? reinterpret_cast<char*>(p.c_mem + urow0 * H) : nullptr;
+    char* co = CELL == CELL_LSTM ? reinterpret_cast<char*>(p.c_out + urow0 * H) : nullptr;
+    float hold[16], cold[CELL == CELL_LSTM ? 16 : 1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const size_t ro = ((e & 3) + 8 * (e >> 2)) * rowb;  // uniform
+      if constexpr (CELL == CELL_GRU) hold[e] = *reinterpret_cast<const float*>(hm + ro + lane_off);
+      if constexpr (CELL == CELL_LSTM) cold[e] = *reinterpret_cast<const float*>(cm + ro + lane_off);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const size_t ro = ((e & 3) + 8 * (e >> 2)) * rowb;
+      float a[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) a[q] = acc[s][q][e];
+      float c = CELL == CELL_LSTM ? cold[e] : 0.0f;
+      const float hy = gate_math<CELL>(a, bi, bhh, CELL == CELL_GRU ? hold[e] : 0.0f, c);
+      *reinterpret_cast<float*>(ho + ro + lane_off) = hy;
+      if constexpr (CELL == CELL_LSTM) *reinterpret_cast<float*>(co + ro + lane_off) = c;
+      if (write_mem) {
+        *reinterpret_cast<float*>(hm + ro + lane_off) = hy;
+        if constexpr (CELL == CELL_LSTM) *reinterpret_cast<float*>(cm + ro + lane_off) = c;
+      }
+    }
+  }
+}
+
 template <int MODE, int CELL, int JSUB, int WC, bool IDS, bool PIPE = false>
 __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel(SplitArgs p) {
   using C = Cell<CELL>;
@@ -503,6 +588,14 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
 
     }
     // ---- epilogue: gates, state update, stores (same accumulator layout as the fp32 kernel).
+    bool fast = false;
+    if constexpr (!IDS) fast = row0 + kRows <= p.M && p.saved == nullptr;
+    if (fast) {
+      epilogue_full_tile<CELL, JSUB, JW>(p, acc, row0 + rg * 32, j0 + cg * JW, lr, lh,
+                                         p.mem_write && JC == H);
+      continue;
+    }
+    // General path (last tile, redirected rows, gate values saved for the backward pass).
     // Row addresses are "uniform row base + lane offset", so that no per-element 64-bit
     // address is kept alive across the K loop.
 #pragma unroll
@@ -541,7 +634,7 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
           const float az = acc[s][1][e] + (bi[1] + bhh[1]);
           const float pr = 1.0f + __expf(ar < -40.0f ? 40.0f : -ar);
           const float pz = 1.0f + __expf(az < -40.0f ? 40.0f : -az);
-          const float inv = __frcp_rn(pr * pz);
+          const float inv = rcpf_(pr * pz);
           const float r = pz * inv;
           const float z = pr * inv;
           const float hn = acc[s][3][e] + bhh[2];
