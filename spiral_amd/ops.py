@@ -7,6 +7,7 @@ NodeMemory read/write of implicitTimeModels.py:48-54,153-156.
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -329,7 +330,7 @@ class GatAggregate(torch.autograd.Function):
         csr = g.csr()
         n, width = ft.shape
         d = width // heads
-        need_grad = any(ctx.needs_input_grad[:3])
+        need_grad = _needs_grad(ctx, 3)
         ft_c, el_c, er_c = ft.detach().contiguous(), el.detach().contiguous(), er.detach().contiguous()
         attn, raw = edge_softmax_scores(csr, el_c, er_c, slope, need_grad)
         out = torch.empty(csr.n_rows, width, dtype=torch.float32, device=ft.device)
@@ -395,10 +396,31 @@ def gat_aggregate(g, ft: torch.Tensor, el: torch.Tensor, er: torch.Tensor, heads
     nv.require_cuda(ft, el, er, bias)
     if ft.dtype != torch.float32 or ft.dim() != 2 or ft.shape[1] % heads:
         raise nv.SpmiError(f"gat_aggregate expects float32 [N, heads*D] features, got {tuple(ft.shape)}")
-    return GatAggregate.apply(ft, el, er, bias, g, heads, float(negative_slope), act, float(act_slope))
+    return _apply_tracked(GatAggregate, (ft, el, er, bias), ft, el, er, bias, g, heads, float(negative_slope), act,
+                          float(act_slope))
 
 
 # --------------------------------------------------------------------------- recurrent cells
+# Inside Function.forward grad mode is always off and ctx.needs_input_grad is True for every
+# parameter that requires grad, torch.no_grad() or not.  Whether a call is really tracked
+# (and must keep gate values for its backward) is therefore decided by the wrappers below,
+# before apply(): an inference step must not allocate and write M x 5H floats per layer.
+_track = threading.local()
+
+
+def _apply_tracked(fn, tensors, *args):
+    prev = getattr(_track, "on", True)
+    _track.on = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    try:
+        return fn.apply(*args)
+    finally:
+        _track.on = prev
+
+
+def _needs_grad(ctx, n: int) -> bool:
+    return getattr(_track, "on", True) and any(ctx.needs_input_grad[:n])
+
+
 def _rows(mem: torch.Tensor, ids: Optional[torch.Tensor], m: int) -> torch.Tensor:
     """Dense [M,H] view/copy of the memory rows a batch reads (GEMM operand)."""
     if ids is None:
@@ -500,7 +522,7 @@ class GruCell(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        need_grad = any(ctx.needs_input_grad[:5])
+        need_grad = _needs_grad(ctx, 5)
         saved = torch.empty(m, 5 * hd, dtype=torch.float32, device=x.device) if need_grad else None
         h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
         if _fused_ok(xd, w_hh):
@@ -544,7 +566,7 @@ class LstmCell(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        need_grad = any(ctx.needs_input_grad[:5])
+        need_grad = _needs_grad(ctx, 5)
         fused = _fused_ok(xd, w_hh)
         h_old = _rows(h_mem, ids, m) if (need_grad or not fused) else None
         if need_grad and (mem_write or ids is not None):
@@ -590,7 +612,7 @@ class RnnCell(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
         m, hd = x.shape[0], w_hh.shape[1]
         xd = x.detach()
-        need_grad = any(ctx.needs_input_grad[:5])
+        need_grad = _needs_grad(ctx, 5)
         fused = _fused_ok(xd, w_hh)
         h_old = _rows(h_mem, ids, m) if (need_grad or not fused) else None
         if need_grad and (mem_write or ids is not None):
@@ -686,15 +708,18 @@ def gru_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
     mem_write).  Returns the new hidden state [M, H] (differentiable w.r.t. x and weights;
     the memory is a constant, as in the reference where it never carries a graph)."""
     _check_cell_args(x, h_mem, ids)
-    return GruCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write)
+    return _apply_tracked(GruCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids,
+                          mem_write)
 
 
 def lstm_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids=None, mem_write=True):
     _check_cell_args(x, h_mem, ids)
     _check_cell_args(x, c_mem, ids)
-    return LstmCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write)
+    return _apply_tracked(LstmCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem,
+                          c_mem, ids, mem_write)
 
 
 def rnn_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
     _check_cell_args(x, h_mem, ids)
-    return RnnCell.apply(x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write)
+    return _apply_tracked(RnnCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids,
+                          mem_write)

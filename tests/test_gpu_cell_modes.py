@@ -95,3 +95,25 @@ def test_f16x3_out_of_range_operand_is_loud(dev):
         assert torch.isfinite(out[:7]).all() and torch.isfinite(out[8:]).all()
     finally:
         ops.CELL_GEMM = old
+
+
+def test_inference_step_keeps_no_gate_values(dev):
+    """Under no_grad a cell must not allocate the per-row gate values of its backward pass,
+    even though its weights require grad (ctx.needs_input_grad says True regardless)."""
+    m, h = 65_536, 128
+    w_ih, w_hh, b_ih, b_hh = (t.requires_grad_() for t in _params(3, h, h, dev, seed=9))
+    x = torch.randn(m, h, device=dev)
+    mem = torch.zeros(m, h, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem)
+    torch.cuda.synchronize()
+    extra = torch.cuda.max_memory_allocated() - base
+    assert extra < 2.5 * m * h * 4, extra          # the output and the small weight planes, not 5 H per row
+    # and with tracking on, the backward still works through the same entry point
+    mem.zero_()
+    out = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem)
+    out.sum().backward()
+    assert w_ih.grad is not None and torch.isfinite(w_ih.grad).all()
