@@ -59,8 +59,10 @@ const char* spmi_last_error(void);
  * Degrees.  Replaces DGLGraph.in_degrees() (spiro/dtdg/types.py:241) and the
  * in_degrees()/out_degrees() calls inside dgl GraphConv.forward reached from
  * staticGraphEncoder.py:113,116.  deg[v] = number of occurrences of v in
- * ids[0..E); multi-edges count every time.  No atomics: keys-only radix sort
- * followed by run boundaries, so the result is exact and reproducible.
+ * ids[0..E); multi-edges count every time.  Exact and reproducible: for
+ * N <= 2^20 one radix pass groups the ids into buckets of 4096 nodes and a
+ * workgroup per bucket counts them in LDS (integer LDS atomics only); larger N
+ * take a keys-only radix sort followed by run boundaries (no atomics at all).
  * `status` (device, 1 x int32, caller-zeroed) is set non-zero when an id is
  * outside [0,N); the offending id is clamped so no access leaves the buffers.
  * ---------------------------------------------------------------------- */

@@ -297,6 +297,35 @@ __global__ void norm_kernel(const int32_t* __restrict__ indptr, int64_t N, int m
   }
 }
 
+// ---- degrees by one bucket pass + LDS counters ---------------------------------------
+// Counting needs no order inside a bucket: after ONE scatter pass on the top bits the keys of
+// a 4096-node bucket are contiguous, and a workgroup counts their low 12 bits in LDS
+// (integer LDS atomics: exact, order-independent) and writes that bucket's degrees with
+// plain stores.  Two passes over the keys instead of the three full passes of the sort.
+constexpr int kCountLow = 12;
+constexpr int kCountThreads = 1024;
+
+__global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ totals, int64_t N,
+    int64_t* __restrict__ deg) {
+  __shared__ uint32_t s_hist[1 << kCountLow];
+  __shared__ uint32_t s_start;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < (1 << kCountLow); j += kCountThreads) s_hist[j] = 0;
+  if (tid == 0) s_start = 0;
+  __syncthreads();
+  if (tid < b) atomicAdd(&s_start, totals[tid]);  // at most 256 buckets: b <= 255 < blockDim
+  __syncthreads();
+  const uint32_t start = s_start, count = totals[b];
+  for (uint32_t i = tid; i < count; i += kCountThreads)
+    atomicAdd(&s_hist[keys[start + i] & ((1u << kCountLow) - 1u)], 1u);
+  __syncthreads();
+  const int64_t node0 = static_cast<int64_t>(b) << kCountLow;
+  for (int j = tid; j < (1 << kCountLow); j += kCountThreads)
+    if (node0 + j < N) deg[node0 + j] = s_hist[j];
+}
+
 __global__ void norm_from_degree_kernel(const int64_t* __restrict__ deg, int64_t N, int mode,
                                         float* __restrict__ norm) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -499,7 +528,7 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
   SPMI_REQUIRE(ws_bytes >= spmi_degree_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
                "spmi_degree: workspace %zu < required %zu", ws_bytes,
                spmi_degree_workspace_bytes(E, N));
-  const SortShape sh = sort_shape(E, N);
+  SortShape sh = sort_shape(E, N);
   const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
   const size_t np = spmi::align_up(sizeof(int32_t) * (size_t)(N + 1), 256);
   char* p = static_cast<char*>(ws);
@@ -511,6 +540,25 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
   b.hist = reinterpret_cast<uint32_t*>(p + 2 * e4 + np);
   b.totals = reinterpret_cast<uint32_t*>(
       p + 2 * e4 + np + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
+  if (N <= (int64_t{1} << (kCountLow + 8))) {
+    // up to 256 buckets of 4096 nodes: one scatter pass on the bucket number, then LDS counts
+    const int n_buckets = static_cast<int>((N + (1 << kCountLow) - 1) >> kCountLow);
+    int bits = 1;
+    while ((1 << bits) < n_buckets) ++bits;
+    const dim3 grid(sh.n_tiles), block(kThreads);
+    radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(ids, E, (uint32_t)N, kCountLow, bits, b.hist,
+                                                       sh.n_tiles, status);
+    SPMI_CHECK_LAUNCH("radix_hist(degree)");
+    radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
+    SPMI_CHECK_LAUNCH("radix_scan(degree)");
+    radix_scatter_kernel<int64_t, true, 0><<<grid, block, 0, st>>>(
+        ids, nullptr, nullptr, nullptr, b.keys[0], nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow,
+        bits, b.hist, b.totals, sh.n_tiles, status);
+    SPMI_CHECK_LAUNCH("radix_scatter(degree)");
+    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg);
+    SPMI_CHECK_LAUNCH("bucket_count");
+    return SPMI_OK;
+  }
   if (int rc = run_sort<0>(ids, nullptr, E, N, 1, sh, b, status, st)) return rc;
   const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
   csr_finalize_kernel<<<grid, kThreads, 0, st>>>(b.keys[0], E, N, indptr);

@@ -73,6 +73,19 @@ def test_out_of_range_id_is_reported(dev):
         G.degree(torch.tensor([-1, 2], dtype=torch.int64, device=dev), 5)
 
 
+@pytest.mark.parametrize("n,e", [(1, 7), (4096, 50_000), (4097, 50_000), (300_000, 2_000_000), (1 << 20, 3_000_000),
+                                 ((1 << 20) + 1, 3_000_000)])
+def test_degree_bucket_and_sort_paths(dev, n, e):
+    """Up to 2^20 nodes degrees come from one bucket pass + LDS counters, above from the
+    keys-only sort; both must equal a bincount, hubs included."""
+    rng = np.random.default_rng(n + e)
+    ids = rng.integers(0, n, e, dtype=np.int64)
+    ids[: e // 3] = ids[0]                      # a hub holding a third of all entries
+    ids[e // 3: e // 2] = n - 1                 # and the last node
+    got = G.degree(torch.from_numpy(ids).to(dev), n).cpu().numpy()
+    assert np.array_equal(got, np.bincount(ids, minlength=n))
+
+
 def test_deferred_build_reports_at_first_use(dev):
     """A CSR built with defer=True hands back control before the device has answered; the
     verdict on the ids arrives with ready(), and so with any aggregation on the graph."""
