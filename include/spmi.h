@@ -292,12 +292,15 @@ int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * w_planes = spmi_split_f16x3(W, N, K).  The weight planes stay in LDS and x streams from
  * HBM straight into the matrix cores, so the kernel runs at memory speed:
  * M*(K+N)*4 bytes.  act: 0 none, 1 relu, 2 leaky_relu(slope).  bias nullable.
+ * row_scale (nullable, device [M]): row r of the result is multiplied by row_scale[r]
+ * last, which is how GraphConv applies its source normaliser (`feat_src * norm` in dgl
+ * GraphConv.forward) without a pass of its own or a per-edge weight.
  * ---------------------------------------------------------------------- */
 int spmi_gemm_rows_supported(int64_t K, int64_t N);
 int spmi_gemm_rows(const float* x /*device [M, K], row stride ldx*/, int64_t ldx, int64_t M, int64_t K,
-                   const void* w_planes, int64_t N, const float* bias /*device [N] or null*/, int act,
-                   float slope, float* out /*device [M, N], row stride ldo*/, int64_t ldo,
-                   void* stream);
+                   const void* w_planes, int64_t N, const float* bias /*device [N] or null*/,
+                   const float* row_scale /*device [M] or null*/, int act, float slope,
+                   float* out /*device [M, N], row stride ldo*/, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------
  * Attention encoder.  Replace what dgl GATConv.forward runs on the graph

@@ -34,6 +34,7 @@ struct RowsArgs {
   int64_t M;
   const uint4* wp;  // weight planes, [KT][3][2][N][8] fp16
   const float* bias;
+  const float* row_scale;  // nullable: out row r is multiplied by row_scale[r] at the end
   int act;          // 0 none, 1 relu, 2 leaky_relu
   float slope;
   float* out;
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
 
+    // the row scales of this tile, fetched under the matrix work (rows past M: clamped)
+    float rs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int64_t r = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      r = r < p.M ? r : p.M - 1;
+      rs[e] = p.row_scale ? p.row_scale[r] : 1.0f;
+    }
+
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       f16x8 p0, p1, p2;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
         float v = acc[nb][e] + bias[nb];
         if (p.act == 1) v = fmaxf(v, 0.0f);
         else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
-        o[voff + nb * 32] = v;
+        o[voff + nb * 32] = v * rs[e];
       }
     }
     tile = next;
@@ -190,7 +200,8 @@ int spmi_gemm_rows_supported(int64_t K, int64_t N) {
 }
 
 int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void* w_planes, int64_t N,
-                   const float* bias, int act, float slope, float* out, int64_t ldo, void* stream) {
+                   const float* bias, const float* row_scale, int act, float slope, float* out,
+                   int64_t ldo, void* stream) {
   SPMI_REQUIRE(spmi_gemm_rows_supported(K, N), SPMI_ERR_UNSUPPORTED,
                "spmi_gemm_rows: K must be 32, 64 or 128 and N 32, 64, 96 or 128 (K=%lld N=%lld)",
                (long long)K, (long long)N);
@@ -206,7 +217,7 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
                    (reinterpret_cast<uintptr_t>(w_planes) & 15u) == 0,
                SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: x and w_planes must be 16-byte aligned");
   RowsArgs a{};
-  a.x = x; a.ldx = ldx; a.M = M; a.wp = static_cast<const uint4*>(w_planes); a.bias = bias;
+  a.x = x; a.ldx = ldx; a.M = M; a.wp = static_cast<const uint4*>(w_planes); a.bias = bias; a.row_scale = row_scale;
   a.act = act; a.slope = slope; a.out = out; a.ldo = ldo;
   hipStream_t st = spmi::as_stream(stream);
   if (K == 32) return launch_n<2>(a, N, st);

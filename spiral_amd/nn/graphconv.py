@@ -22,7 +22,7 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
-from spiral_amd.ops import gcn_aggregate, rows_times_weight
+from spiral_amd.ops import gcn_aggregate, graphconv_inference, rows_times_weight
 
 
 def _classify_activation(act) -> Tuple[Optional[str], float, Optional[Callable]]:
@@ -90,7 +90,15 @@ class GraphConv(nn.Module):
 
         if weight is not None and weight.dtype != feat.dtype:
             weight = weight.to(feat.dtype)  # bf16 feature storage: the projection runs in bf16
-        if self._in_feats >= self._out_feats:
+        tracked = torch.is_grad_enabled() and (feat.requires_grad or (weight is not None and weight.requires_grad)
+                                               or (self.bias is not None and self.bias.requires_grad))
+        rst = None
+        if (self._in_feats >= self._out_feats and weight is not None and edge_weight is None and not tracked
+                and feat.dtype == torch.float32):
+            rst = graphconv_inference(graph, feat, weight, self._norm, self.bias, code, slope)
+        if rst is not None:
+            pass
+        elif self._in_feats >= self._out_feats:
             if weight is not None:
                 feat = rows_times_weight(feat, weight)
             rst = gcn_aggregate(graph, feat, self._norm, self.bias, edge_weight, code, slope)

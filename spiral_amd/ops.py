@@ -126,18 +126,39 @@ def _gemm_rows_ok(x: torch.Tensor, k: int, n: int) -> bool:
 
 
 def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              act: Optional[str] = None, slope: float = 0.01) -> torch.Tensor:
-    """act(x @ weight_nk.T + bias) for x [rows, K] and weight_nk [N, K] in one launch of
-    spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`."""
+              act: Optional[str] = None, slope: float = 0.01,
+              row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ weight_nk.T + bias) * row_scale[:, None] for x [rows, K] and weight_nk [N, K] in
+    one launch of spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`."""
     n, k = weight_nk.shape
     planes = split_f16x3(weight_nk)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    if row_scale is not None and (row_scale.dtype != torch.float32 or row_scale.numel() != x.shape[0]
+                                  or not row_scale.is_contiguous()):
+        raise nv.SpmiError("gemm_rows: row_scale must be a contiguous float32 vector with one entry per row")
     with torch.cuda.device(x.device):
         out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
         nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), x.stride(0), x.shape[0], k, nv.ptr(planes), n,
-                                         nv.ptr(b), _ACT_CODES[act], float(slope), nv.ptr(out), n,
-                                         nv.stream()), "spmi_gemm_rows")
+                                         nv.ptr(b), nv.ptr(row_scale), _ACT_CODES[act], float(slope),
+                                         nv.ptr(out), n, nv.stream()), "spmi_gemm_rows")
     return out
+
+
+def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
+                        bias: Optional[torch.Tensor], act: Optional[str], slope: float
+                        ) -> Optional[torch.Tensor]:
+    """GraphConv without autograd when the projection runs on spmi_gemm_rows: the source
+    normaliser is applied to the projected rows in the GEMM's epilogue (as DGL does with
+    `feat_src * norm`), so the aggregation needs no per-edge weight and the snapshot no
+    gather of one.  Returns None when the shapes are not covered."""
+    if norm not in ("both", "left", "right", "none") or not _gemm_rows_ok(feat, weight.shape[0], weight.shape[1]):
+        return None
+    mode = 0 if norm == "both" else 1
+    scale = g.norm("out", mode) if norm in ("both", "left") else None
+    rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale)
+    dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
+    return aggregate(g.csr(wait=False), rst, None, None, dst_scale,
+                     None if bias is None else bias.detach(), act, slope)
 
 
 def _mm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

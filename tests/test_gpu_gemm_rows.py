@@ -94,5 +94,48 @@ def test_out_of_range_operand_is_loud_and_bad_shapes_are_refused(dev):
     assert not nv.lib().spmi_gemm_rows_supported(48, 32)
     assert not nv.lib().spmi_gemm_rows_supported(128, 256)
     with pytest.raises(nv.SpmiError):
-        nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), 32, 4096, 48, nv.ptr(w), 32, None, 0, 0.0,
+        nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), 32, 4096, 48, nv.ptr(w), 32, None, None, 0, 0.0,
                                          nv.ptr(out), 32, nv.stream()), "spmi_gemm_rows")
+
+
+def test_row_scale(dev):
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(5003, 64, generator=gen).to(dev)
+    w = (torch.randn(96, 64, generator=gen) * 0.1).to(dev)
+    b = torch.randn(96, generator=gen).to(dev)
+    rs = (torch.rand(5003, generator=gen) + 0.1).to(dev)
+    got = ops.gemm_rows(x, w, b, "relu", 0.0, rs)
+    want = _ref(x, w, b, "relu") * rs.double().cpu()[:, None]
+    assert float((got.double().cpu() - want).abs().max()) < 1e-5
+    with pytest.raises(nv.SpmiError):
+        ops.gemm_rows(x, w, b, None, 0.0, rs[:100])
+
+
+@pytest.mark.parametrize("norm", ["both", "left", "right", "none"])
+def test_graphconv_inference_path_equals_tracked_path(dev, norm):
+    """Without autograd GraphConv scales the projected rows in the GEMM and aggregates with no
+    per-edge weight; with autograd it streams a per-edge weight.  Same numbers to 1e-5."""
+    from oracle import oracle as orc
+    from spiral_amd import graph as G
+    from spiral_amd.core.types import GraphConv
+
+    n, e = 6000, 50_000
+    src, dst = orc.powerlaw_snapshot(n, e, t=3)
+    g = G.SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    torch.manual_seed(5)
+    conv = GraphConv(64, 64, norm=norm, activation=torch.nn.functional.leaky_relu,
+                     allow_zero_in_degree=True).to(dev)
+    x = torch.randn(n, 64, device=dev)
+    calls = []
+    real = ops.graphconv_inference
+    import spiral_amd.nn.graphconv as gc_mod
+    gc_mod.graphconv_inference = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            fast = conv(g, x)
+        tracked = conv(g, x)
+    finally:
+        gc_mod.graphconv_inference = real
+    assert len(calls) == 1 and tracked.requires_grad and not fast.requires_grad
+    scale = float(tracked.detach().abs().max())
+    assert float((fast - tracked.detach()).abs().max()) < 1e-5 * max(scale, 1.0)
