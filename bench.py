@@ -344,7 +344,8 @@ def main():
         return out
 
     # ---- N>1 forward: one snapshot in two halves, the exchange in between ----------------
-    # front(t): CSR + norms, layer 1 on the replicated input (no exchange), projection of
+    # front(t): CSR + norms, layer 1 on the replicated input (no exchange; aggregated
+    # into the local block first, projected afterwards), projection of
     # layer 2, start of its all-gather.  back(t): layer-2 aggregation, recurrent update,
     # MLP.  step t runs front(t) and then back(t-1): the rows of snapshot t travel while
     # snapshot t-1 is finished and snapshot t+1 is started.  Outputs equal the plain order
@@ -362,7 +363,7 @@ def main():
         shard.norm("out", 0)
         if ev:
             ev[1].record()
-        h = par.graphconv_aggregate(model.conv1, shard, par.graphconv_project(model.conv1, x_repl))
+        h = par.graphconv_replicated(model.conv1, shard, x_repl)
         if ev:
             ev[2].record()
         pending = par.gather_rows_async(par.graphconv_project(model.conv2, h), part, None, payload)

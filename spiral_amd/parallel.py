@@ -202,8 +202,15 @@ def _finish(conv, rst: torch.Tensor, code, slope, unfused) -> torch.Tensor:
     import torch.nn.functional as F
 
     weight = conv.weight
+    tracked = torch.is_grad_enabled() and (rst.requires_grad or any(
+        p is not None and p.requires_grad for p in (weight, conv.bias)))
+    if (weight is not None and not tracked and code in (None, "relu", "leaky_relu")
+            and ops._gemm_rows_ok(rst, weight.shape[0], weight.shape[1])):
+        # projection, bias and activation in one pass over the rows
+        rst = ops.gemm_rows(rst, weight.detach().t(), conv.bias, code, slope)
+        return rst if unfused is None else unfused(rst)
     if weight is not None:
-        rst = torch.addmm(conv.bias, rst, weight) if conv.bias is not None else rst @ weight
+        rst = ops.rows_times_weight(rst, weight, conv.bias)
     elif conv.bias is not None:
         rst = rst + conv.bias
     if code == "relu":
@@ -222,7 +229,7 @@ def sharded_graphconv(conv, shard: ShardedSnapshot, feat_local: torch.Tensor) ->
     code, slope, unfused = _split_activation(conv)
     if conv._in_feats >= conv._out_feats:
         if conv.weight is not None:
-            feat_local = feat_local @ conv.weight
+            feat_local = ops.rows_times_weight(feat_local, conv.weight)
         rst = sharded_aggregate(shard, feat_local, norm, conv.bias, code, slope)
         return rst if unfused is None else unfused(rst)
     return _finish(conv, sharded_aggregate(shard, feat_local, norm), code, slope, unfused)
@@ -276,8 +283,19 @@ def graphconv_project(conv, feat: torch.Tensor) -> torch.Tensor:
     multiplies first, X itself otherwise).  Row-local, so it applies to a rank's own rows
     or to a replicated matrix alike."""
     if conv._in_feats >= conv._out_feats and conv.weight is not None:
-        return feat @ conv.weight
+        return ops.rows_times_weight(feat, conv.weight)
     return feat
+
+
+def graphconv_replicated(conv, shard: ShardedSnapshot, x_full: torch.Tensor) -> torch.Tensor:
+    """A layer whose input every rank holds in full (`replicate_rows`): no exchange, and no
+    redundant work either, because the rows are aggregated into this rank's block first and
+    only the block is projected: A (X W) = (A X) W, the order DGL itself takes when
+    in_feats <= out_feats.  Projecting the replicated matrix first would cost every rank the
+    GEMM of the whole graph."""
+    code, slope, unfused = _split_activation(conv)
+    rst = ops.gcn_aggregate(shard, x_full, conv._norm, None, None, None)
+    return _finish(conv, rst, code, slope, unfused)
 
 
 def graphconv_aggregate(conv, shard: ShardedSnapshot, z_full: torch.Tensor) -> torch.Tensor:

@@ -107,7 +107,7 @@ def _worker(rank, world, port, results):
                 s_np, d_np = orc.powerlaw_snapshot(n, 30_000, t=t, k_dst=4.0)
                 sh = par.ShardedSnapshot.from_global(torch.from_numpy(s_np).to(dev),
                                                      torch.from_numpy(d_np).to(dev), part, deg_group)
-                h1 = par.graphconv_aggregate(conv1, sh, par.graphconv_project(conv1, x_repl))
+                h1 = par.graphconv_replicated(conv1, sh, x_repl)   # aggregate into the block, then project
                 z2 = par.graphconv_project(conv2, h1)
                 in_flight.append((sh, par.gather_rows_async(z2, part),
                                   par.gather_rows_async(z2, part, None, torch.bfloat16)))
@@ -128,6 +128,15 @@ def _worker(rank, world, port, results):
         par.allreduce_gradients(conv1)
         out.update(y1=y1.detach().cpu().numpy(), gw1=conv1.weight.grad.cpu().numpy(),
                    gb1=conv1.bias.grad.cpu().numpy())
+        # the same layer in the order that projects only the local block: with and without autograd
+        conv1.zero_grad()
+        y1r = par.graphconv_replicated(conv1, shard, x_repl)
+        (y1r ** 2).sum().backward()
+        par.allreduce_gradients(conv1)
+        with torch.no_grad():
+            y1r_ng = par.graphconv_replicated(conv1, shard, x_repl)
+        out.update(y1r=y1r.detach().cpu().numpy(), y1r_ng=y1r_ng.cpu().numpy(),
+                   gw1r=conv1.weight.grad.cpu().numpy())
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -186,4 +195,7 @@ def test_two_ranks_on_one_gpu_equal_single_gpu(dev):
         lo, hi = bounds[r], bounds[r + 1]
         assert rel(results[r]["y1"], y1[lo:hi]) < 1e-5
         assert rel(results[r]["gw1"], conv1.weight.grad) < 1e-5
+        assert rel(results[r]["y1r"], y1[lo:hi]) < 1e-5
+        assert rel(results[r]["y1r_ng"], y1[lo:hi]) < 1e-5
+        assert rel(results[r]["gw1r"], conv1.weight.grad) < 1e-5
         assert rel(results[r]["gb1"], conv1.bias.grad) < 1e-5
