@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kKeysPerThread = 16;
+constexpr int kKeysPerThread = 8;
 constexpr int kTile = kThreads * kKeysPerThread;  // keys per workgroup per pass
 constexpr int kMaxDigits = 256;
 
