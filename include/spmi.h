@@ -288,7 +288,9 @@ int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * staticGraphEncoder.py:113,116; likewise SGConv / SAGEConv's fc layers) and the Linear
  * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} and
  * N in {32, 64, 96, 128}.  fp32 results from the fp16 matrix cores with the three-plane
- * operand format of spmi_cell_f16x3_fwd (same accuracy, same domain |v| <= 65504);
+ * operand format of spmi_cell_f16x3_fwd (same accuracy).  The rows of x may hold any finite
+ * fp32 value (each row is scaled by a power of two before it is split and its results by the
+ * inverse; a non-finite entry makes its own row non-finite); |W| <= 1023;
  * w_planes = spmi_split_f16x3(W, N, K).  The weight planes stay in LDS and x streams from
  * HBM straight into the matrix cores, so the kernel runs at memory speed:
  * M*(K+N)*4 bytes.  act: 0 none, 1 relu, 2 leaky_relu(slope).  bias nullable.

@@ -5,8 +5,12 @@
 //
 // fp32 in, fp32 out, on the fp16 matrix cores with the three-plane operand format of
 // cell_split.hip (p0 = fp16(v), p1 = fp16(v/64), p2 = fp16((v - p0)*64); x*w = p0*p0 + p1*p2 +
-// p2*p1, fp32 accumulation): sums land closer to float64 than an fp32 FMA chain, operands
-// must lie within +-65504 (a larger one turns its output row into inf/NaN).
+// p2*p1, fp32 accumulation): sums land closer to float64 than an fp32 FMA chain.  The rows of
+// X may hold any finite fp32 value: a wave has the whole row in registers before it starts
+// on it, so every row is multiplied by a power of two that puts its largest magnitude in
+// [2^13, 2^14) (exact), and the accumulators by the inverse power at the end.  Raw node
+// features such as degree counts can exceed fp16's 65504; without the scaling such a row
+// would come out as inf/NaN.  The weights must lie within +-65504 / 64.
 //
 // The shape makes this an HBM-bound kernel (M*(K+N)*4 bytes against 3*2*M*K*N flops on
 // matrix cores that are ~15x faster than that), so the design is about the stream of X:
@@ -108,6 +112,25 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
 
+    // Power-of-two scale of this lane's row (the lane pair l, l ^ 32 holds one row): the
+    // largest magnitude goes to [2^13, 2^14), a zero or non-finite row is left alone.
+    float up, down;
+    {
+      float m = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][0].x), fabsf(a[t][0].y)), fmaxf(fabsf(a[t][0].z), fabsf(a[t][0].w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][1].x), fabsf(a[t][1].y)), fmaxf(fabsf(a[t][1].z), fabsf(a[t][1].w))));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
+      const bool ok = ex != 0 && ex != 255;                                   // normal and finite
+      const int shift = ok ? 127 + 13 - ex : 0;                               // 2^shift * m in [2^13, 2^14)
+      const int sh = shift > 100 ? 100 : (shift < -100 ? -100 : shift);
+      up = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
+      down = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
+    }
+
     // the row scales of this tile, fetched under the matrix work (rows past M: clamped)
     float rs[16];
 #pragma unroll
@@ -120,7 +143,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       f16x8 p0, p1, p2;
-      split8(a[t][0], a[t][1], p0, p1, p2);
+      {
+        float4 lo = a[t][0], hi = a[t][1];
+        lo.x *= up; lo.y *= up; lo.z *= up; lo.w *= up;
+        hi.x *= up; hi.y *= up; hi.z *= up; hi.w *= up;
+        split8(lo, hi, p0, p1, p2);
+      }
       a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
       a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
       // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
@@ -149,9 +177,13 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
       const int ur = (e & 3) + 8 * (e >> 2);
       if (row0 + ur + 4 * lh >= p.M) continue;
       float* o = obase + ur * p.ldo;
+      // the inverse scale of output row ur + 4 lh sits in lane ur + 4 lh (either half)
+      const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+      const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+      const float dn = lh ? d1 : d0;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float v = acc[nb][e] + bias[nb];
+        float v = acc[nb][e] * dn + bias[nb];
         if (p.act == 1) v = fmaxf(v, 0.0f);
         else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
         o[voff + nb * 32] = v * rs[e];

@@ -112,7 +112,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 # Projections of a tall matrix by a small weight: "f16x3" = libspmi's memory-speed kernel on
-# the fp16 matrix cores (three-plane operands, fp32-chain accuracy, operands within +-65504),
+# the fp16 matrix cores (three-plane operands, fp32-chain accuracy; rows of any finite
+# magnitude, they are scaled by a power of two in the kernel; weights within +-1023),
 # "library" = torch.mm (hipBLASLt, fp32 matrix instruction).
 DENSE_GEMM = "f16x3"
 GEMM_ROWS_MIN_ROWS = 4096

@@ -84,13 +84,32 @@ def test_layers_route_through_it_and_gradients_match(dev):
         assert float((got.double().cpu() - want).abs().max()) < 1e-5 * scale
 
 
-def test_out_of_range_operand_is_loud_and_bad_shapes_are_refused(dev):
-    x = torch.ones(4096, 32, device=dev)
-    x[100, 5] = 7.0e4
-    w = torch.full((32, 32), 0.01, device=dev)
+def test_rows_of_any_magnitude_and_bad_shapes(dev):
+    """Rows are scaled by a power of two before they are split, so values far outside fp16's
+    range (degree counts, unnormalised features) and tiny rows come out at fp32 accuracy;
+    non-finite input stays non-finite in its own row only."""
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(4096, 32, generator=gen)
+    x[100] *= 7.0e4
+    x[101] *= 1.0e30
+    x[102] *= 1.0e-30
+    x[103, 5] = 3.0e9                      # one huge entry among ordinary ones
+    x[104] = 0.0
+    x = x.to(dev)
+    w = (torch.randn(32, 32, generator=gen) * 0.1).to(dev)
+    out = ops.gemm_rows(x, w).double().cpu()
+    want = _ref(x, w, None, None)
+    scale = want.abs().amax(dim=1, keepdim=True).clamp(min=1e-300)
+    assert torch.isfinite(out).all()
+    assert float(((out - want).abs() / scale).max()) < 2e-6
+    assert float(out[104].abs().max()) == 0.0
+    x[200, 3] = float("inf")
+    x[201, 0] = float("nan")
     out = ops.gemm_rows(x, w)
-    assert not torch.isfinite(out[100]).any()
-    assert torch.isfinite(out[:100]).all() and torch.isfinite(out[101:]).all()
+    assert not torch.isfinite(out[200]).any() and not torch.isfinite(out[201]).any()
+    keep = torch.ones(4096, dtype=torch.bool)
+    keep[200] = keep[201] = False
+    assert torch.isfinite(out[keep.to(dev)]).all()
     assert not nv.lib().spmi_gemm_rows_supported(48, 32)
     assert not nv.lib().spmi_gemm_rows_supported(128, 256)
     with pytest.raises(nv.SpmiError):
