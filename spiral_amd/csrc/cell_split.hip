@@ -367,7 +367,8 @@ __device__ __forceinline__ void piped_step(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
 // Gate math of one state element; `h` / `c` are the old state, the new one is returned.
 template <int CELL>
 __device__ __forceinline__ float gate_math(const float (&a)[Cell<CELL>::NACC], const float (&bi)[Cell<CELL>::NG],
-                                           const float (&bhh)[Cell<CELL>::NG], float h, float& c) {
+                                           const float (&bhh)[Cell<CELL>::NG], float h, float& c,
+                                           float (&sv)[6]) {
   if constexpr (CELL == CELL_GRU) {
     // r and z from one reciprocal: with p = 1 + e^-a, q = 1 + e^-b and i = 1/(p q),
     // r = q i and z = p i.  The exponents are clamped at 40 so that p q stays finite.
@@ -380,25 +381,30 @@ __device__ __forceinline__ float gate_math(const float (&a)[Cell<CELL>::NACC], c
     const float inv = rcpf_(pr * pz);
     const float r = pz * inv;
     const float z = pr * inv;
-    const float n = tanhf_(a[2] + bi[2] + r * (a[3] + bhh[2]));
+    const float hn = a[3] + bhh[2];
+    const float n = tanhf_(a[2] + bi[2] + r * hn);
+    sv[0] = r; sv[1] = z; sv[2] = n; sv[3] = hn; sv[4] = h;
     return n + z * (h - n);
   } else if constexpr (CELL == CELL_LSTM) {
     const float ig = sigmoidf_(a[0] + (bi[0] + bhh[0]));
     const float fg = sigmoidf_(a[1] + (bi[1] + bhh[1]));
     const float gg = tanhf_(a[2] + (bi[2] + bhh[2]));
     const float og = sigmoidf_(a[3] + (bi[3] + bhh[3]));
+    sv[4] = c;
     c = fg * c + ig * gg;
-    return og * tanhf_(c);
+    const float tc = tanhf_(c);
+    sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[5] = tc;
+    return og * tc;
   } else {
     return tanhf_(a[0] + (bi[0] + bhh[0]));
   }
 }
 
-// Epilogue of a full tile whose state rows are contiguous and whose gate values nobody
-// wants back (inference): no per-element bounds test, the sixteen old-state values of a
-// 32-column block loaded before the math, every address a uniform row base plus one 32-bit
-// lane offset.
-template <int CELL, int JSUB, int JW>
+// Epilogue of a full tile whose state rows are contiguous: no per-element bounds test, the
+// sixteen old-state values of a 32-column block loaded before the math, every address a
+// uniform row base plus one 32-bit lane offset.  SAVE: the gate values go to `saved` for the
+// backward pass (GRU r, z, n, hn, h; LSTM i, f, g, o, c, tanh(c')).
+template <int CELL, int JSUB, int JW, bool SAVE>
 __device__ __forceinline__ void epilogue_full_tile(const SplitArgs& p,
                                                    f32x16 (&acc)[JSUB][Cell<CELL>::NACC],
                                                    int64_t urow0, int jbase, int lr, int lh,
@@ -435,7 +441,15 @@ __device__ __forceinline__ void epilogue_full_tile(const SplitArgs& p,
 #pragma unroll
       for (int q = 0; q < NACC; ++q) a[q] = acc[s][q][e];
       float c = CELL == CELL_LSTM ? cold[e] : 0.0f;
-      const float hy = gate_math<CELL>(a, bi, bhh, CELL == CELL_GRU ? hold[e] : 0.0f, c);
+      float sv[6];
+      const float hy = gate_math<CELL>(a, bi, bhh, CELL == CELL_GRU ? hold[e] : 0.0f, c, sv);
+      if constexpr (SAVE && CELL != CELL_RNN) {
+        constexpr int NS = CELL == CELL_GRU ? 5 : 6;
+        char* sb = reinterpret_cast<char*>(p.saved + urow0 * (NS * H)) + NS * ro +
+                   static_cast<uint32_t>(4 * lh * NS * H + j) * 4u;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<float*>(sb + q * rowb) = sv[q];
+      }
       *reinterpret_cast<float*>(ho + ro + lane_off) = hy;
       if constexpr (CELL == CELL_LSTM) *reinterpret_cast<float*>(co + ro + lane_off) = c;
       if (write_mem) {
@@ -589,13 +603,17 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
     }
     // ---- epilogue: gates, state update, stores (same accumulator layout as the fp32 kernel).
     bool fast = false;
-    if constexpr (!IDS) fast = row0 + kRows <= p.M && p.saved == nullptr;
+    if constexpr (!IDS) fast = row0 + kRows <= p.M;
     if (fast) {
-      epilogue_full_tile<CELL, JSUB, JW>(p, acc, row0 + rg * 32, j0 + cg * JW, lr, lh,
-                                         p.mem_write && JC == H);
+      if (p.saved == nullptr || CELL == CELL_RNN)
+        epilogue_full_tile<CELL, JSUB, JW, false>(p, acc, row0 + rg * 32, j0 + cg * JW, lr, lh,
+                                                  p.mem_write && JC == H);
+      else
+        epilogue_full_tile<CELL, JSUB, JW, true>(p, acc, row0 + rg * 32, j0 + cg * JW, lr, lh,
+                                                 p.mem_write && JC == H);
       continue;
     }
-    // General path (last tile, redirected rows, gate values saved for the backward pass).
+    // General path (last tile, redirected rows).
     // Row addresses are "uniform row base + lane offset", so that no per-element 64-bit
     // address is kept alive across the K loop.
 #pragma unroll

@@ -578,8 +578,14 @@ class GruCell(torch.autograd.Function):
         g_x = g_gi @ w_ih if ctx.needs_input_grad[0] else None
         g_wih = gemm_tn(g_gi, xd) if ctx.needs_input_grad[1] else None
         g_whh = gemm_tn(g_gh, h_old) if ctx.needs_input_grad[2] else None
-        g_bih = g_gi.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        g_bhh = g_gh.sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        g_bih = g_bhh = None
+        if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            # the r and z columns of g_gi and g_gh are the same numbers: sum them once
+            g_bih = g_gi.sum(0)
+            if ctx.needs_input_grad[4]:
+                g_bhh = torch.cat([g_bih[: 2 * hd], g_gh[:, 2 * hd:].sum(0)])
+            if not ctx.needs_input_grad[3]:
+                g_bih = None
         return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
 
 
