@@ -8,6 +8,7 @@ NodeMemory read/write of implicitTimeModels.py:48-54,153-156.
 from __future__ import annotations
 
 import threading
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -128,11 +129,14 @@ def _gemm_rows_ok(x: torch.Tensor, k: int, n: int) -> bool:
 
 def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Tensor] = None,
               act: Optional[str] = None, slope: float = 0.01,
-              row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+              row_scale: Optional[torch.Tensor] = None, planes: Optional[torch.Tensor] = None
+              ) -> torch.Tensor:
     """act(x @ weight_nk.T + bias) * row_scale[:, None] for x [rows, K] and weight_nk [N, K] in
-    one launch of spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`."""
+    one launch of spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`.  `planes`:
+    `weight_planes(...)` of the same weight, for callers that hold it across calls."""
     n, k = weight_nk.shape
-    planes = split_f16x3(weight_nk)
+    if planes is None:
+        planes = split_f16x3(weight_nk)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     if row_scale is not None and (row_scale.dtype != torch.float32 or row_scale.numel() != x.shape[0]
                                   or not row_scale.is_contiguous()):
@@ -156,7 +160,8 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
         return None
     mode = 0 if norm == "both" else 1
     scale = g.norm("out", mode) if norm in ("both", "left") else None
-    rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale)
+    rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale,
+                    planes=weight_planes(weight, "f16x3", True))
     dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
     return aggregate(g.csr(wait=False), rst, None, None, dst_scale,
                      None if bias is None else bias.detach(), act, slope)
@@ -165,14 +170,14 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
 def _mm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ w (+ bias), w [K, N], no autograd."""
     if _gemm_rows_ok(x, w.shape[0], w.shape[1]):
-        return gemm_rows(x, w.detach().t(), bias)
+        return gemm_rows(x, w.detach().t(), bias, planes=weight_planes(w, "f16x3", True))
     return torch.addmm(bias, x, w) if bias is not None else x @ w
 
 
 def _mm_nk(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ weight.T (+ bias), weight [N, K], no autograd."""
     if _gemm_rows_ok(x, weight.shape[1], weight.shape[0]):
-        return gemm_rows(x, weight.detach(), bias)
+        return gemm_rows(x, weight.detach(), bias, planes=weight_planes(weight, "f16x3"))
     return torch.nn.functional.linear(x, weight, bias)
 
 
@@ -183,7 +188,7 @@ class _RowsTimesWeight(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return _mm(x.detach(), w.detach(), None if bias is None else bias.detach())
+        return _mm(x.detach(), w, None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, g):
@@ -202,7 +207,7 @@ def rows_times_weight(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
         return torch.addmm(bias, x, w) if bias is not None else x @ w
     if not (x.requires_grad or w.requires_grad or (bias is not None and bias.requires_grad)) \
             or not torch.is_grad_enabled():
-        return _mm(x.detach(), w.detach(), None if bias is None else bias.detach())
+        return _mm(x.detach(), w, None if bias is None else bias.detach())
     return _RowsTimesWeight.apply(x, w, bias)
 
 
@@ -213,7 +218,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _mm_nk(x.detach(), weight.detach(), None if bias is None else bias.detach())
+        return _mm_nk(x.detach(), weight, None if bias is None else bias.detach())
 
     @staticmethod
     def backward(ctx, g):
@@ -232,7 +237,7 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         return torch.nn.functional.linear(x, weight, bias)
     if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad
                                            or (bias is not None and bias.requires_grad)):
-        return _mm_nk(x.detach(), weight.detach(), None if bias is None else bias.detach())
+        return _mm_nk(x.detach(), weight, None if bias is None else bias.detach())
     return _Linear.apply(x, weight, bias)
 
 
@@ -513,13 +518,32 @@ def split_f16x3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Operand planes of a weight are kept per tensor object for as long as the tensor is alive and
+# unchanged (same version counter, same storage address): an inference loop then launches no
+# split kernel and no transpose copy per call, a training loop re-splits after every update.
+_plane_cache: dict = {}
+
+
+def weight_planes(w: torch.Tensor, kind: str = "f16x3", transposed: bool = False) -> torch.Tensor:
+    """`split_f16x3` / `split_bf16x3` of `w` (of `w.T` when `transposed`), cached."""
+    slot_id = (id(w), kind, transposed)
+    key = (w._version, w.data_ptr(), tuple(w.shape), w.stride(), w.device)
+    slot = _plane_cache.get(slot_id)
+    if slot is not None and slot[0]() is w and slot[1] == key:
+        return slot[2]
+    src = w.detach().t() if transposed else w.detach()
+    planes = split_f16x3(src) if kind == "f16x3" else split_bf16x3(src)
+    ref = weakref.ref(w, lambda _r, k=slot_id: _plane_cache.pop(k, None))
+    _plane_cache[slot_id] = (ref, key, planes)
+    return planes
+
+
 def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h_out, c_out, saved):
     """Both gate GEMMs + gates + memory write-back in one launch (csrc/cell_split.hip or
     csrc/cell_fused.hip, see CELL_GEMM)."""
     if CELL_GEMM in ("bf16x3", "f16x3"):
-        split, name = ((split_bf16x3, "spmi_cell_split_fwd") if CELL_GEMM == "bf16x3"
-                       else (split_f16x3, "spmi_cell_f16x3_fwd"))
-        ws_ih, ws_hh = split(w_ih), split(w_hh)
+        name = "spmi_cell_split_fwd" if CELL_GEMM == "bf16x3" else "spmi_cell_f16x3_fwd"
+        ws_ih, ws_hh = weight_planes(w_ih, CELL_GEMM), weight_planes(w_hh, CELL_GEMM)
         with torch.cuda.device(x.device):
             nv.check(getattr(nv.lib(), name)(
                 _CELL_CODE[kind], nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh),

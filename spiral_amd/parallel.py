@@ -207,7 +207,8 @@ def _finish(conv, rst: torch.Tensor, code, slope, unfused) -> torch.Tensor:
     if (weight is not None and not tracked and code in (None, "relu", "leaky_relu")
             and ops._gemm_rows_ok(rst, weight.shape[0], weight.shape[1])):
         # projection, bias and activation in one pass over the rows
-        rst = ops.gemm_rows(rst, weight.detach().t(), conv.bias, code, slope)
+        rst = ops.gemm_rows(rst, weight.detach().t(), conv.bias, code, slope,
+                            planes=ops.weight_planes(weight, "f16x3", True))
         return rst if unfused is None else unfused(rst)
     if weight is not None:
         rst = ops.rows_times_weight(rst, weight, conv.bias)

@@ -158,3 +158,27 @@ def test_graphconv_inference_path_equals_tracked_path(dev, norm):
     assert len(calls) == 1 and tracked.requires_grad and not fast.requires_grad
     scale = float(tracked.detach().abs().max())
     assert float((fast - tracked.detach()).abs().max()) < 1e-5 * max(scale, 1.0)
+
+
+def test_weight_planes_cache_follows_the_weight(dev):
+    """Planes are reused while the weight object is unchanged and rebuilt after an in-place
+    update, a re-assignment of .data, or for another tensor at the same address."""
+    w = torch.nn.Parameter(torch.randn(64, 64, device=dev) * 0.1)
+    x = torch.randn(4096, 64, device=dev)
+    p1 = ops.weight_planes(w, "f16x3", True)
+    assert ops.weight_planes(w, "f16x3", True) is p1
+    assert ops.weight_planes(w, "f16x3", False) is not p1            # other orientation: own entry
+    with torch.no_grad():
+        y1 = ops.rows_times_weight(x, w)
+        w.mul_(2.0)                                                   # version bump
+        y2 = ops.rows_times_weight(x, w)
+        assert torch.allclose(y2, 2.0 * y1, rtol=1e-5, atol=1e-6)
+        w.data = torch.randn(64, 64, device=dev) * 0.1                # new storage, same object
+        y3 = ops.rows_times_weight(x, w)
+    want = x.double().cpu() @ w.detach().double().cpu()
+    assert float((y3.double().cpu() - want).abs().max()) < 1e-5
+    n_before = len(ops._plane_cache)
+    del w
+    import gc
+    gc.collect()
+    assert len(ops._plane_cache) < n_before                           # entries die with the tensor
