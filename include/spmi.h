@@ -270,9 +270,15 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * An operand v travels as p0 = fp16(v), p1 = fp16(v / 64), p2 = fp16((v - p0) * 64) and
  * x*w = p0(x)*p0(w) + p1(x)*p2(w) + p2(x)*p1(w) with fp32 accumulation: each product is off
  * by at most about 2^-20 |x w|, and sums of 256 terms measure 3-8x closer to float64 than an
- * fp32 FMA chain.  Domain: |v| <= 65504 for x, the state and the weights; a larger operand
- * turns into infinity and its output row into inf/NaN (spmi_cell_split_fwd has no such
- * limit).  ws_ih / ws_hh come from spmi_split_f16x3 (same tiling as spmi_split_bf16x3:
+ * fp32 FMA chain.  Domain: the state and the weights within +-65504 (a larger operand turns
+ * into infinity and its output row into inf/NaN; spmi_cell_split_fwd has no such limit).  The
+ * rows of x may hold any finite value: with x_bounded = 0 a workgroup first reads its rows of
+ * x and stages a row that reaches 2^15 scaled by a power of two (its largest entry lands in
+ * [2^13, 2^14)); the partial sums are scaled back, exactly, before the state terms are added.
+ * Entries of such a row resolve to 2^-44 of the row's largest.  x_bounded = 1 skips that pass
+ * for callers that know |x| < 2^15, e.g. when x is the output of another recurrent layer.
+ * Weights below 2^-9 in magnitude keep an absolute resolution of 2^-31 rather than the relative
+ * one.  ws_ih / ws_hh come from spmi_split_f16x3 (same tiling as spmi_split_bf16x3:
  * [cols/16][3][2][rows][8] 16-bit words).  Arguments and shape limits as
  * spmi_cell_split_fwd. */
 int spmi_split_f16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
@@ -280,7 +286,7 @@ int spmi_split_f16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64
 int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
                         const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
-                        float* c_out, int mem_write, float* saved, void* stream);
+                        float* c_out, int mem_write, float* saved, int x_bounded, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].

@@ -19,8 +19,12 @@
 // for |v| down to about 2^-8; below that they lose relative but not absolute accuracy (the
 // matrix cores keep subnormal fp16 inputs, scripts/probe/mfma_f16_denorm.hip).  Measured
 // against float64 the sums are 3-8x closer than an fp32 FMA chain of the same length.
-// Domain: |v| <= 65504.  A larger operand becomes infinity in p0 and the output of its row
-// is inf/NaN, as in any fp16 matrix pipeline; the bf16x3 mode has no such limit.
+// Domain: the state and the weights within +-65504.  The rows of x may hold any finite value:
+// unless the caller declares them bounded, a workgroup first reads its 128 rows of x, and a
+// row whose largest magnitude reaches 2^15 is staged multiplied by the power of two that
+// brings it to [2^13, 2^14); the accumulators of that row are multiplied by the inverse power
+// after the last x term, before the first state term.  GraphConv outputs of graphs with
+// count-valued features (degrees, citation counts) do get that large.
 //
 // Replaces the same reference lines as cell_fused.hip: torch.nn.GRU / LSTM / RNN as driven
 // by SequentialDecoder.forward / LSTM.forward (spiro/dtdg/models/decoder/torch/
@@ -92,6 +96,7 @@ struct SplitArgs {
   float* c_out;
   int mem_write;
   float* saved;
+  int x_bounded;  // the caller vouches for |x| < 2^15: skip the row-magnitude pass
 };
 
 // v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal: a full division sequence
@@ -154,6 +159,7 @@ template <int APT, int BPT>
 struct StageRegs {
   float4 a[APT];
   uint4 b[BPT];
+  float sc[APT];  // power-of-two scale of the row each a[i] belongs to (1 unless the row is huge)
 };
 
 // Global loads of one K-step into registers.  Addresses are "wave-uniform base + small
@@ -178,7 +184,8 @@ __device__ __forceinline__ void store_stage(const StageRegs<APT, BPT>& r, char* 
                                             const int (&a_dst)[APT], int tid) {
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
-    const float v[4] = {r.a[i].x, r.a[i].y, r.a[i].z, r.a[i].w};
+    const float m = MODE == MODE_F16X3 ? r.sc[i] : 1.0f;
+    const float v[4] = {r.a[i].x * m, r.a[i].y * m, r.a[i].z * m, r.a[i].w * m};
     if constexpr (MODE == MODE_F16X3) {
       f16x4 p0, p1, p2;
 #pragma unroll
@@ -285,8 +292,8 @@ __device__ __forceinline__ void stage_slice(int k, const StageRegs<APT, BPT>& r,
   if (k < 5 * APT) {
     const int i = k / 5, part = k % 5;
     if (part < 2) {
-      const float v0 = part == 0 ? r.a[i].x : r.a[i].z;
-      const float v1 = part == 0 ? r.a[i].y : r.a[i].w;
+      const float v0 = (part == 0 ? r.a[i].x : r.a[i].z) * r.sc[i];
+      const float v1 = (part == 0 ? r.a[i].y : r.a[i].w) * r.sc[i];
       _Float16 h, m, l;
       split_f16x3(v0, h, m, l);
       p0[i][2 * part] = h;
@@ -514,6 +521,53 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
   const int a_rd = (lh * kRows + rg * 32 + lr) * 16;
   const int b_rd = A_BYTES + (lh * NC + cg * JW + lr) * 16;
 
+  // Row magnitudes of x (fp16 planes only): the four threads that stage a row find its largest
+  // |x|; a row that reaches 2^15 gets the power-of-two scale that brings it to [2^13, 2^14) and
+  // its inverse is left in LDS for the epilogue.  Every other row keeps scale 1.
+  float row_sc[APT];
+  float* s_inv = reinterpret_cast<float*>(smem + 2 * STAGE + 1024);  // [kRows], behind the stages
+  bool any_scaled = false;
+#pragma unroll
+  for (int i = 0; i < APT; ++i) row_sc[i] = 1.0f;
+  if constexpr (MODE == MODE_F16X3) {
+    if (!p.x_bounded) {
+      const int n_steps = p.I / kBK;
+      bool mine = false;
+      float rmax[APT];
+#pragma unroll
+      for (int i = 0; i < APT; ++i) rmax[i] = 0.0f;
+      for (int t0 = 0; t0 < n_steps; t0 += 4) {  // 4 * APT loads in flight
+        float4 v[4][APT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < APT; ++i)
+            v[u][i] = t0 + u < n_steps ? *reinterpret_cast<const float4*>(xbase + ax[i] + (t0 + u) * kBK)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < APT; ++i)
+            rmax[i] = fmaxf(rmax[i], fmaxf(fmaxf(fabsf(v[u][i].x), fabsf(v[u][i].y)),
+                                           fmaxf(fabsf(v[u][i].z), fabsf(v[u][i].w))));
+      }
+#pragma unroll
+      for (int i = 0; i < APT; ++i) {
+        float m = rmax[i];
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
+        const bool big = ex >= 127 + 15 && ex != 255;                         // finite, >= 2^15
+        const int sh = big ? ex - (127 + 13) : 0;                             // m * 2^-sh in [2^13, 2^14)
+        row_sc[i] = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
+        const int idx = tid + i * THREADS;
+        if ((idx & 3) == 0) s_inv[idx >> 2] = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
+        mine |= big;
+      }
+      any_scaled = __syncthreads_or(mine);
+    }
+  }
+
   for (int j0 = 0; j0 < H; j0 += JC) {
     // B staging: chunk c -> (plane, k half) c / NC, tile row c % NC.  The weights are stored
     // [K/16][plane][k half][n][8], so a K-step advances every offset by 3*GH*16.
@@ -537,6 +591,29 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
         for (int e = 0; e < 16; ++e) acc[s][a][e] = 0.0f;
 
     StageRegs<APT, BPT> regs;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) regs.sc[i] = row_sc[i];
+
+    // Rows of x that were scaled down: their partial sums are scaled back between the x terms
+    // and the state terms (a power of two, exact), so the state terms never see the factor.
+    auto unscale_rows = [&]() {
+      if (any_scaled) {  // rare
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float inv = s_inv[rg * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+#pragma unroll
+          for (int sb = 0; sb < JSUB; ++sb)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) acc[sb][q][e] *= inv;
+        }
+      }
+    };
+
+    // The registers hold a tile of the state from here on: staged as it is.
+    auto state_tile = [&]() {
+#pragma unroll
+      for (int i = 0; i < APT; ++i) regs.sc[i] = 1.0f;
+    };
 
     const int tiles_x = p.I / kBK;
     const int tiles_h = H / kBK;
@@ -548,7 +625,7 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
       load_stage<APT, BPT>(regs, xbase, ax, 0, p.ws_ih, boff, 0);
       store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem, a_dst, tid);
       if (1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, kBK, p.ws_ih, boff, bstep);
-      else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
+      else { load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0); state_tile(); }
       __syncthreads();
       int buf = 0;
       // two loops, one per phase: a single loop that picks the accumulator set by a branch
@@ -559,11 +636,14 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
             acc, cur + a_rd, cur + b_rd, regs, smem + (buf ^ 1) * STAGE, dump, a_dst, tid);
         const int s2 = s + 2;  // the registers are free again: fetch the step after next
         if (s2 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, s2 * kBK, p.ws_ih, boff, s2 * bstep);
-        else if (s2 < total)
+        else if (s2 < total) {
           load_stage<APT, BPT>(regs, hbase, ah, (s2 - tiles_x) * kBK, p.ws_hh, boff, (s2 - tiles_x) * bstep);
+          state_tile();
+        }
         __syncthreads();
         buf ^= 1;
       }
+      unscale_rows();
       for (int t = 0; t + 1 < tiles_h; ++t) {
         const char* cur = smem + buf * STAGE;
         piped_step<CELL, JSUB, JC, A_PLANE, B_PLANE, true, APT, BPT, B16, THREADS, A_BYTES>(
@@ -582,13 +662,14 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
     int buf = 0;
     for (int t = 0; t < tiles_x; ++t) {
       if (t + 1 < tiles_x) load_stage<APT, BPT>(regs, xbase, ax, (t + 1) * kBK, p.ws_ih, boff, (t + 1) * bstep);
-      else load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0);
+      else { load_stage<APT, BPT>(regs, hbase, ah, 0, p.ws_hh, boff, 0); state_tile(); }
       mfma_stage<MODE, CELL, JSUB, JC, A_PLANE, B_PLANE, false>(acc, smem + buf * STAGE + a_rd,
                                                           smem + buf * STAGE + b_rd);
       store_stage<MODE, APT, BPT, B16, THREADS, A_PLANE, A_BYTES>(regs, smem + (buf ^ 1) * STAGE, a_dst, tid);
       __syncthreads();
       buf ^= 1;
     }
+    unscale_rows();
     for (int t = 0; t < tiles_h; ++t) {
       const bool more = t + 1 < tiles_h;
       if (more) load_stage<APT, BPT>(regs, hbase, ah, (t + 1) * kBK, p.ws_hh, boff, (t + 1) * bstep);
@@ -714,7 +795,7 @@ template <int MODE, int CELL, int JSUB, int WC>
 int launch_config(const SplitArgs& a, hipStream_t st) {
   constexpr int NC = Cell<CELL>::NG * JSUB * 32 * WC;
   constexpr bool PIPE = MODE == MODE_F16X3 && JSUB == 2;  // staging between the MFMAs: 3-4 % faster
-  constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2) + (PIPE ? 1024 : 0);
+  constexpr size_t lds = 2 * 3 * (kRows + NC) * (kBK * 2) + (MODE == MODE_F16X3 ? 1024 + 4 * kRows : 0);
   static_assert(lds <= 160 * 1024, "LDS stage does not fit");
   auto plain = split_cell_kernel<MODE, CELL, JSUB, WC, false, PIPE>;
   auto gathered = split_cell_kernel<MODE, CELL, JSUB, WC, true, PIPE>;
@@ -756,7 +837,8 @@ template <int MODE>
 int cell_split_fwd(const char* name, int cell, const float* x, int64_t ldx, int64_t I,
                    const void* ws_ih, const void* ws_hh, const float* b_ih, const float* b_hh,
                    float* h_mem, float* c_mem, const int64_t* ids, int64_t M, int64_t H,
-                   float* h_out, float* c_out, int mem_write, float* saved, void* stream) {
+                   float* h_out, float* c_out, int mem_write, float* saved, int x_bounded,
+                   void* stream) {
   SPMI_REQUIRE(cell >= CELL_GRU && cell <= CELL_RNN, SPMI_ERR_INVALID_ARG, "%s: bad cell code %d",
                name, cell);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "%s: bad M=%lld", name,
@@ -781,6 +863,7 @@ int cell_split_fwd(const char* name, int cell, const float* x, int64_t ldx, int6
   a.b_ih = b_ih; a.b_hh = b_hh;
   a.h_mem = h_mem; a.c_mem = c_mem; a.ids = ids; a.M = M; a.H = static_cast<int>(H);
   a.h_out = h_out; a.c_out = c_out; a.mem_write = mem_write; a.saved = saved;
+  a.x_bounded = x_bounded;
   hipStream_t st = spmi::as_stream(stream);
   if (cell == CELL_GRU) return launch_split<MODE, CELL_GRU>(a, st);
   if (cell == CELL_LSTM) return launch_split<MODE, CELL_LSTM>(a, st);
@@ -804,15 +887,16 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
                         float* c_out, int mem_write, float* saved, void* stream) {
   return cell_split_fwd<MODE_BF16X3>("spmi_cell_split_fwd", cell, x, ldx, I, ws_ih, ws_hh, b_ih, b_hh,
-                                     h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, stream);
+                                     h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, 1, stream);
 }
 
 int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
                         const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
-                        float* c_out, int mem_write, float* saved, void* stream) {
+                        float* c_out, int mem_write, float* saved, int x_bounded, void* stream) {
   return cell_split_fwd<MODE_F16X3>("spmi_cell_f16x3_fwd", cell, x, ldx, I, ws_ih, ws_hh, b_ih, b_hh,
-                                    h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, stream);
+                                    h_mem, c_mem, ids, M, H, h_out, c_out, mem_write, saved, x_bounded,
+                                    stream);
 }
 
 }  // extern "C"

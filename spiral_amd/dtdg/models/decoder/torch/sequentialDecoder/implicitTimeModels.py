@@ -177,7 +177,7 @@ class GRU(SequentialDecoder):
     def _step(self, x, ids):
         for k in range(self.n_layers):
             x = ops.gru_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,
-                             mem_write=self.training_mode)
+                             mem_write=self.training_mode, x_bounded=k > 0)  # layer k > 0 reads a cell's output
             x = self._between_layers(x, k)
         return x
 
@@ -198,7 +198,7 @@ class RNN(SequentialDecoder):
     def _step(self, x, ids):
         for k in range(self.n_layers):
             x = ops.rnn_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,
-                             mem_write=self.training_mode)
+                             mem_write=self.training_mode, x_bounded=k > 0)
             x = self._between_layers(x, k)
         return x
 
@@ -221,6 +221,7 @@ class LSTM(SequentialDecoder):
     def _step(self, x, ids):
         for k in range(self.n_layers):
             x, _c = ops.lstm_cell(x, *self._layer_params(k), self.memory_h.memory[k],
-                                  self.memory_c.memory[k], ids, mem_write=self.training_mode)
+                                  self.memory_c.memory[k], ids, mem_write=self.training_mode,
+                                  x_bounded=k > 0)
             x = self._between_layers(x, k)
         return x

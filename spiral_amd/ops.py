@@ -435,13 +435,14 @@ def gat_aggregate(g, ft: torch.Tensor, el: torch.Tensor, er: torch.Tensor, heads
 _track = threading.local()
 
 
-def _apply_tracked(fn, tensors, *args):
-    prev = getattr(_track, "on", True)
+def _apply_tracked(fn, tensors, *args, x_bounded: bool = False):
+    prev = getattr(_track, "on", True), getattr(_track, "x_bounded", False)
     _track.on = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+    _track.x_bounded = bool(x_bounded)
     try:
         return fn.apply(*args)
     finally:
-        _track.on = prev
+        _track.on, _track.x_bounded = prev
 
 
 def _needs_grad(ctx, n: int) -> bool:
@@ -484,8 +485,9 @@ def _fused_ok(x, w_hh) -> bool:
 # How the fused layer step multiplies:
 #   "f16x3"  = every operand as the fp16 planes fp16(v), fp16(v/64), fp16((v - fp16(v))*64);
 #              three matrix instructions per term; sums land 3-8x closer to float64 than an
-#              fp32 FMA chain.  Operands must lie within +-65504 (x, state, weights): a
-#              larger one overflows to infinity and shows up as inf/NaN in its output row;
+#              fp32 FMA chain.  The state and the weights must lie within +-65504 (a larger
+#              one shows up as inf/NaN in its output row); rows of x of any finite magnitude
+#              are scaled by a power of two inside the kernel;
 #   "bf16x3"  = fp32 operands split exactly into three bf16 pieces, six piece products per
 #               term (fp32-accurate over the whole fp32 range, twice the matrix work);
 #   "fp32"    = the fp32 matrix instruction (an exact fp32 FMA chain).
@@ -549,6 +551,7 @@ def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h
                 _CELL_CODE[kind], nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh),
                 nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem), nv.ptr(ids), x.shape[0],
                 w_hh.shape[1], nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
+                *(() if CELL_GEMM == "bf16x3" else (int(getattr(_track, "x_bounded", False)),)),
                 nv.stream()), name)
         return
     if CELL_GEMM != "fp32":
@@ -754,24 +757,26 @@ def gru_cell_dense(x, h, w_ih, w_hh, b_ih=None, b_hh=None):
     return GruCellDense.apply(x, h, w_ih, w_hh, b_ih, b_hh)
 
 
-def gru_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
+def gru_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True, x_bounded=False):
     """One GRU step for a batch of nodes.  h_mem is one layer of the node memory
     ([n_nodes, H], read at rows `ids`, overwritten there with the detached new state when
     mem_write).  Returns the new hidden state [M, H] (differentiable w.r.t. x and weights;
-    the memory is a constant, as in the reference where it never carries a graph)."""
+    the memory is a constant, as in the reference where it never carries a graph).
+    `x_bounded`: the caller knows |x| < 2^15 (e.g. x is another cell's output), which spares the
+    default kernel its pass over the magnitudes of x; same for lstm_cell and rnn_cell."""
     _check_cell_args(x, h_mem, ids)
     return _apply_tracked(GruCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids,
-                          mem_write)
+                          mem_write, x_bounded=x_bounded)
 
 
-def lstm_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids=None, mem_write=True):
+def lstm_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids=None, mem_write=True, x_bounded=False):
     _check_cell_args(x, h_mem, ids)
     _check_cell_args(x, c_mem, ids)
     return _apply_tracked(LstmCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem,
-                          c_mem, ids, mem_write)
+                          c_mem, ids, mem_write, x_bounded=x_bounded)
 
 
-def rnn_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True):
+def rnn_cell(x, w_ih, w_hh, b_ih, b_hh, h_mem, ids=None, mem_write=True, x_bounded=False):
     _check_cell_args(x, h_mem, ids)
     return _apply_tracked(RnnCell, (x, w_ih, w_hh, b_ih, b_hh), x.contiguous(), w_ih, w_hh, b_ih, b_hh, h_mem, ids,
-                          mem_write)
+                          mem_write, x_bounded=x_bounded)

@@ -81,14 +81,90 @@ def test_f16x3_planes(dev):
     assert ((p1 * 64 - wd).abs() <= wd.abs() * 2.0 ** -11 + 2.0 ** -19).all()
 
 
-def test_f16x3_out_of_range_operand_is_loud(dev):
-    """An operand beyond fp16's range must not produce a plausible wrong number."""
+def test_f16x3_rows_of_x_of_any_magnitude(dev):
+    """GraphConv outputs of graphs with count-valued features exceed fp16's range.  The default
+    kernel scales such rows of x by a power of two (the state is left alone): results must match
+    a float64 evaluation, and a caller's wrong promise of bounded input must fail loudly
+    (inf/NaN in that row, every other row untouched), not quietly."""
+    old, ops.CELL_GEMM = ops.CELL_GEMM, "f16x3"
+    try:
+        m, i, h = 300, 64, 128
+        gen = torch.Generator().manual_seed(4)
+        x = torch.randn(m, i, generator=gen)
+        w_ih = torch.randn(3 * h, i, generator=gen) * 0.1
+        # columns 3 and 40 of the weights: small multiples of 2^-14, so that the outliers below
+        # leave the gates out of saturation and the expected value is sensitive to them
+        small = torch.randint(-4, 5, (3 * h, 2), generator=gen).float() * 2.0 ** -14
+        w_ih[:, 3], w_ih[:, 40] = small[:, 0], small[:, 1]
+        big_rows = (7, 8, 9, 200, 299)
+        x[7, 3] = 4.0e4                                     # just past 2^15
+        x[8, 3], x[8, 40] = 7.0e4, -6.6e4                   # past fp16's largest number
+        x[9, 40] = 1.0e5
+        x[200, 3] = -9.0e4                                  # second 128-row tile
+        x[299] *= 3.0e8                                     # saturates every gate
+        w_hh = torch.randn(3 * h, h, generator=gen) * 0.1
+        b_ih, b_hh = torch.randn(3 * h, generator=gen) * 0.1, torch.randn(3 * h, generator=gen) * 0.1
+        h0 = torch.randn(m, h, generator=gen)
+        xd, hd = x.double(), h0.double()
+        gi = xd @ w_ih.double().t() + b_ih.double()
+        gh = hd @ w_hh.double().t() + b_hh.double()
+        r = torch.sigmoid(gi[:, :h] + gh[:, :h])
+        z = torch.sigmoid(gi[:, h:2 * h] + gh[:, h:2 * h])
+        n = torch.tanh(gi[:, 2 * h:] + r * gh[:, 2 * h:])
+        want = (1 - z) * n + z * hd
+        to = lambda t: t.to(dev)
+        mem = to(h0.clone())
+        with torch.no_grad():
+            out = ops.gru_cell(to(x), to(w_ih), to(w_hh), to(b_ih), to(b_hh), mem)
+        assert torch.isfinite(out).all()
+        err = (out.double().cpu() - want).abs()
+        assert float(err.max()) < 2e-5, [float(err[r_].max()) for r_ in big_rows]
+        assert torch.equal(mem, out)
+        mem = to(h0.clone())
+        with torch.no_grad():
+            bad = ops.gru_cell(to(x), to(w_ih), to(w_hh), to(b_ih), to(b_hh), mem, x_bounded=True)
+        for row in (8, 9, 200, 299):                        # beyond 65504: no fp16 value
+            assert not torch.isfinite(bad[row]).all()
+        keep = torch.ones(m, dtype=torch.bool)
+        keep[list(big_rows)] = False
+        assert float((bad.double().cpu()[keep] - want[keep]).abs().max()) < 2e-5
+        # LSTM and RNN share the staging code; a saturated and an unsaturated big row each
+        for cell, g in (("lstm", 4), ("rnn", 1)):
+            w1 = torch.randn(g * h, i, generator=gen) * 0.1
+            w1[:, 3] = torch.randint(-4, 5, (g * h,), generator=gen).float() * 2.0 ** -14
+            w1[:, 40] = 0.0
+            w2 = torch.randn(g * h, h, generator=gen) * 0.1
+            b1, b2 = torch.randn(g * h, generator=gen) * 0.1, torch.randn(g * h, generator=gen) * 0.1
+            pre = xd @ w1.double().t() + b1.double() + hd @ w2.double().t() + b2.double()
+            if cell == "rnn":
+                want = torch.tanh(pre)
+                mem = to(h0.clone())
+                with torch.no_grad():
+                    out = ops.rnn_cell(to(x), to(w1), to(w2), to(b1), to(b2), mem)
+            else:
+                c0 = torch.randn(m, h, generator=gen)
+                ig, fg = torch.sigmoid(pre[:, :h]), torch.sigmoid(pre[:, h:2 * h])
+                gg, og = torch.tanh(pre[:, 2 * h:3 * h]), torch.sigmoid(pre[:, 3 * h:])
+                want = og * torch.tanh(fg * c0.double() + ig * gg)
+                mem, cmem = to(h0.clone()), to(c0.clone())
+                with torch.no_grad():
+                    out = ops.lstm_cell(to(x), to(w1), to(w2), to(b1), to(b2), mem, cmem)
+                    out = out[0] if isinstance(out, tuple) else out
+            assert torch.isfinite(out).all(), cell
+            assert float((out.double().cpu() - want).abs().max()) < 2e-5, cell
+    finally:
+        ops.CELL_GEMM = old
+
+
+def test_f16x3_out_of_range_state_is_loud(dev):
+    """The state has no scaling pass (gate outputs are bounded by 1): a state beyond fp16's
+    range must not produce a plausible wrong number."""
     old, ops.CELL_GEMM = ops.CELL_GEMM, "f16x3"
     try:
         w_ih, w_hh, b_ih, b_hh = _params(3, 32, 32, dev, seed=1)
         x = torch.ones(130, 32, device=dev)
-        x[7, 3] = 1.0e5
         mem = torch.zeros(130, 32, device=dev)
+        mem[7, 3] = 1.0e5
         with torch.no_grad():
             out = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem)
         assert not torch.isfinite(out[7]).all()
