@@ -288,6 +288,24 @@ int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,
                         float* c_out, int mem_write, float* saved, int x_bounded, void* stream);
 
+/* The GRU layer step of spmi_cell_f16x3_fwd (same reference lines: torch.nn.GRU with
+ * seq_len 1 as driven by SequentialDecoder.forward, implicitTimeModels.py:144-158, with
+ * NodeMemory.get_memory / update_memory, :48-54) for the case the hot loop runs: ids = every
+ * node, no gate values kept.  Same operand format, same gate functions, results equal to
+ * spmi_cell_f16x3_fwd's up to the order of the matrix instructions; different data movement:
+ * a workgroup keeps the r, z, n weight columns of 32 hidden units in LDS for its lifetime and
+ * streams row tiles of x and the old state straight from memory into the matrix cores, so
+ * no weight is staged per tile.  Rows are read by H / 32 workgroups and written in column
+ * slices, hence NOT in place: h_out [M, H] must overlap neither h_in [M, H] nor x; a caller
+ * that owns the node memory keeps two slabs per layer and swaps them.  Supported: I = H = 128
+ * (spmi_gru_rows_supported).  ws_ih / ws_hh from spmi_split_f16x3; b_ih / b_hh nullable;
+ * x_bounded as in spmi_cell_f16x3_fwd. */
+int spmi_gru_rows_supported(int64_t I, int64_t H);
+int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t ldx, int64_t I,
+                      const void* ws_ih, const void* ws_hh, const float* b_ih, const float* b_hh,
+                      const float* h_in /*device [M, H]*/, int64_t M, int64_t H,
+                      float* h_out /*device [M, H]*/, int x_bounded, void* stream);
+
 /* ------------------------------------------------------------------------
  * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].
  * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites

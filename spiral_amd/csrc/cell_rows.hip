@@ -1,0 +1,392 @@
+// One GRU layer step over ALL node rows with the gate weights resident in LDS: the inference
+// form of torch.nn.GRU as driven by SequentialDecoder.forward
+// (spiro/dtdg/models/decoder/torch/sequentialDecoder/implicitTimeModels.py:144-158) when ids
+// is every node, so that NodeMemory.get_memory / update_memory (:48-54) read one [M, H] slab
+// and write another.
+//
+// Same arithmetic as the f16x3 mode of cell_split.hip (three fp16 planes per operand, three
+// v_mfma_f32_32x32x16_f16 per term, fp32 accumulation, the same gate functions), different
+// data movement.  cell_split.hip gives a workgroup 128 rows and ALL hidden units, so every
+// workgroup streams the whole weight image (590 KB at I = H = 128) through LDS for 131 KB of
+// rows, and the kernel is bound by that staging.  Here a workgroup owns 32 hidden units:
+// their r, z, n columns of W_ih and W_hh (6 x 128 x 32 weights x 3 planes x 2 B = 144 KB)
+// are loaded into LDS once and stay there, and the workgroup streams row tiles past them:
+//  * x and the old state never touch LDS: the A fragment of the MFMA is eight consecutive k
+//    of one row per lane, i.e. two float4 loads straight from global memory, split into the
+//    three planes in registers (as in gemm_rows.hip);
+//  * a wave owns a tile of 32 rows; its 64 row registers hold x of the tile, are refilled
+//    K-step by K-step with the old state of the same tile while the x terms are multiplied,
+//    and with x of the wave's next tile while the state terms are multiplied: 16 KB per wave
+//    are in flight under the matrix work and there is no barrier in the loop;
+//  * the H / 32 workgroups that hold the column slices of one row range run on the same XCD
+//    (blockIdx -> XCD is round-robin) and walk the same tile sequence, so the rows they all
+//    read come from HBM once and from that XCD's L2 afterwards.
+// A row tile is read by several workgroups and written slice by slice, so the new state
+// cannot overwrite the old one in place: h_out must not overlap h_in (the caller keeps two
+// slabs per layer and swaps them).
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+
+struct GruRowsArgs {
+  const float* x;
+  int64_t ldx;
+  const uint4* ws_ih;  // [I/16][3][2][3H][8] fp16 (spmi_split_f16x3 of weight_ih [3H, I])
+  const uint4* ws_hh;  // [H/16][3][2][3H][8] fp16
+  const float* b_ih;
+  const float* b_hh;
+  const float* h_in;
+  float* h_out;
+  int64_t M;
+  int x_bounded;
+};
+
+__device__ __forceinline__ float rcpf_(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float tanhf_(float v) {
+  const float e = __expf(2.0f * (v > 15.0f ? 15.0f : v));  // NaN stays NaN
+  return 1.0f - 2.0f * rcpf_(e + 1.0f);
+}
+
+// The three planes of eight consecutive k of one row.  p1 is taken from p0 by a packed fp16
+// multiply (equal to fp16(v / 64) wherever p0 / 64 is a normal fp16 number; below that, one
+// more rounding of at most 2^-25) and the residual v - p0 by a mixed-precision fma that reads
+// the fp16 value directly: 24 vector instructions for the eight values.
+template <bool SCALED>
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, float m, f16x8& p0,
+                                       f16x8& p1, f16x8& p2) {
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  if constexpr (SCALED) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] *= m;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) p0[q] = static_cast<_Float16>(v[q]);
+  p1 = p0 * static_cast<_Float16>(0x1p-6f);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float d = __builtin_fmaf(static_cast<float>(p0[q]), -1.0f, v[q]);
+    p2[q] = static_cast<_Float16>(d * 0x1p6f);
+  }
+}
+
+constexpr int kGate = 3 * 1024;   // bytes of one gate's planes in one K-step: [plane 3][k half 2][32][8]
+constexpr int kStep = 3 * kGate;  // bytes of one K-step: r, z, n
+
+// The nine matrix instructions of one K-step, gate by gate: three plane products per gate,
+// smallest terms first.  The weight fragments of a gate are read from LDS while the previous
+// gate's instructions run: `bq` arrives holding the r-gate fragments of this step (read during
+// the previous step) and leaves holding those of the step at `sb_next`.  NACC picks where the
+// n gate goes (x terms and state terms of n are kept apart: the reset gate multiplies only
+// the state part).  The fences keep the reads ahead of the instructions that cover them.
+template <int NACC>
+__device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[4], const f16x8& p0, const f16x8& p1,
+                                           const f16x8& p2, const char* sb, const char* sb_next,
+                                           f16x8 (&bq)[3]) {
+  f16x8 b1[3], b2[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b1[q] = *reinterpret_cast<const f16x8*>(sb + kGate + q * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, bq[1], acc[0], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, bq[2], acc[0], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, bq[0], acc[0], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b2[q] = *reinterpret_cast<const f16x8*>(sb + 2 * kGate + q * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, b1[1], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b1[2], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b1[0], acc[1], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const f16x8*>(sb_next + q * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+  acc[NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, b2[1], acc[NACC], 0, 0, 0);
+  acc[NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b2[2], acc[NACC], 0, 0, 0);
+  acc[NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b2[0], acc[NACC], 0, 0, 0);
+}
+
+// KT = I / 16 = H / 16 K-steps per operand; H / 32 column slices.
+// XB: the caller vouches for |x| < 2^15 (no magnitude pass, no scaling code).
+template <int KT, bool XB>
+__global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
+  constexpr int H = KT * 16;
+  constexpr int GH = 3 * H;
+  constexpr int NS = H / 32;                   // column slices
+  constexpr int B16 = 2 * KT * kStep / 16;     // 16-byte chunks of the slice image
+  static_assert(KT % 2 == 0, "K-steps come in pairs");
+  static_assert(32 % NS == 0, "slices of one row range must fit the workgroups of one XCD");
+  extern __shared__ uint4 smem4[];
+  const char* smem = reinterpret_cast<const char*>(smem4);
+
+  // Workgroup b runs on XCD b % 8.  The NS slices of a row group sit on one XCD.
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % NS;
+  const int group = (b & 7) + 8 * (b / (8 * NS));
+  const int n_groups = gridDim.x / NS;
+  const int j0 = slice * 32;
+
+  const int tid = threadIdx.x;
+  // LDS image [K-step: x steps, then state steps][gate][plane][k half][32][8]; the source
+  // planes are [K-step][plane][k half][3H][8], so 32 consecutive chunks are contiguous.
+  // K order: a lane reads 64 contiguous bytes of its row at a time (half of a 128-byte line,
+  // all four loads back to back, so the line is fetched from L2 once), which feed two K-steps:
+  // K-step 2u + v, lane half lh, slot i stands for k = 32 u + 16 lh + 8 v + i.  The image is
+  // permuted to match: LDS (step 2u + v, half lh) <- source (step 2u + lh, half v).
+  for (int c = tid; c < B16; c += 512) {
+    const int n = c & 31, lh_ = (c >> 5) & 1, q = (c >> 6) % 3, g = (c / 192) % 3, t = c / 576;
+    const uint4* src = t < KT ? p.ws_ih : p.ws_hh;
+    const int s_ = t < KT ? t : t - KT;
+    const int tt = (s_ & ~1) + lh_, hh = s_ & 1;
+    smem4[c] = src[((tt * 3 + q) * 2 + hh) * GH + g * H + j0 + n];
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t n_tiles = (p.M + 31) / 32;
+  const int64_t stride = static_cast<int64_t>(n_groups) * 8;
+  int64_t tile = static_cast<int64_t>(wave) * n_groups + group;
+  if (tile >= n_tiles) return;
+
+  const int j = j0 + lr;
+  const float b_r = (p.b_ih ? p.b_ih[j] : 0.0f) + (p.b_hh ? p.b_hh[j] : 0.0f);
+  const float b_z = (p.b_ih ? p.b_ih[H + j] : 0.0f) + (p.b_hh ? p.b_hh[H + j] : 0.0f);
+  const float b_in = p.b_ih ? p.b_ih[2 * H + j] : 0.0f;
+  const float b_hn = p.b_hh ? p.b_hh[2 * H + j] : 0.0f;
+
+  // Rows past M are clamped to the last row: computed, never stored.
+  auto clamp_row = [&](int64_t t) {
+    const int64_t r = t * 32 + lr;
+    return r < p.M ? r : p.M - 1;
+  };
+
+  // a[t][0..1]: the eight values of K-step t; the four float4 of a[2u], a[2u+1] are 64
+  // contiguous bytes
+  float4 a[KT][2];
+  auto load_pair = [&](const float* src, int u) {
+    const float4* q = reinterpret_cast<const float4*>(src + 32 * u);
+    a[2 * u][0] = q[0];
+    a[2 * u][1] = q[1];
+    a[2 * u + 1][0] = q[2];
+    a[2 * u + 1][1] = q[3];
+  };
+  {
+    const float* src = p.x + clamp_row(tile) * p.ldx + 16 * lh;
+#pragma unroll
+    for (int u = 0; u < KT / 2; ++u) load_pair(src, u);
+  }
+  const char* sb = smem + lh * 512 + lr * 16;
+  f16x8 bq[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const f16x8*>(sb + q * 1024);
+  const int voff = 4 * lh * H + j;
+
+  // hy: the old state of the wave's 32 x 32 output block while a tile is worked on, its new
+  // state from the gate math until it is stored.  Accumulator layout: element e of lane l is
+  // row (e&3) + 8 (e>>2) + 4 (l>>5), column l&31.  The stores of a tile are issued in the
+  // middle of the NEXT tile, so that at the top of the loop only the sixteen row loads of
+  // that tile are outstanding, on the first pass and on every later one: the wait counts the
+  // compiler derives for the loop head then never cover a store.
+  float hy[16];
+  int64_t prev_row0 = 0;
+
+  auto store_tile = [&](int64_t row0) {
+    float* ob = p.h_out + row0 * H;
+    if (row0 + 32 <= p.M) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ob[((e & 3) + 8 * (e >> 2)) * H + voff] = hy[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        if (row0 + ur + 4 * lh < p.M) ob[ur * H + voff] = hy[e];
+      }
+    }
+  };
+
+  auto body = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int64_t next = tile + stride;
+    // the last iteration re-reads its own tile: valid memory, nothing is done with it
+    const float* xn = p.x + clamp_row(next < n_tiles ? next : tile) * p.ldx + 16 * lh;
+    const float* hc = p.h_in + clamp_row(tile) * H + 16 * lh;
+
+    f32x16 acc[4];  // r, z, n (x terms), n (state terms)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+
+    // A row of x whose largest magnitude reaches 2^15 is multiplied by the power of two that
+    // brings it to [2^13, 2^14); its partial sums are scaled back before the state terms.
+    float up = 1.0f, down = 1.0f;
+    bool any_big = false;
+    if constexpr (!XB) {
+      float m = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][0].x), fabsf(a[t][0].y)), fmaxf(fabsf(a[t][0].z), fabsf(a[t][0].w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][1].x), fabsf(a[t][1].y)), fmaxf(fabsf(a[t][1].z), fabsf(a[t][1].w))));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
+      const bool big = ex >= 127 + 15 && ex != 255;                         // finite, >= 2^15
+      const int sh = big ? ex - (127 + 13) : 0;
+      up = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
+      down = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
+      any_big = __any(big);
+    }
+
+    auto x_phase = [&](auto scaled_tag) {
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        f16x8 p0, p1, p2;
+        split8<decltype(scaled_tag)::value>(a[t][0], a[t][1], up, p0, p1, p2);
+        if (t & 1) load_pair(hc, t >> 1);
+        // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
+        // the tile and then needs a second copy of the rows in registers.
+        __builtin_amdgcn_sched_barrier(0);
+        kstep_mfma<2>(acc, p0, p1, p2, sb + t * kStep, sb + (t + 1) * kStep, bq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    x_phase(std::integral_constant<bool, !XB>{});
+
+    if (any_big) {  // rare, wave-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        // the inverse scale of row ur + 4 lh sits in lane ur + 4 lh (either half)
+        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+        const float dn = lh ? d1 : d0;
+        acc[0][e] *= dn;
+        acc[1][e] *= dn;
+        acc[2][e] *= dn;
+      }
+    }
+
+    const int64_t row0 = tile * 32;
+    if constexpr (!FIRST) store_tile(prev_row0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // rows past M read the last row (valid memory; their results are never stored)
+      const float* hb = p.h_in + row0 * H;
+      const int last = static_cast<int>(p.M - 1 - row0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        hy[e] = hb[(ur < last ? ur : last) * H + j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      f16x8 p0, p1, p2;
+      split8<false>(a[t][0], a[t][1], 1.0f, p0, p1, p2);
+      if (t & 1) load_pair(xn, t >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      kstep_mfma<3>(acc, p0, p1, p2, sb + (KT + t) * kStep, sb + (t + 1 < KT ? KT + t + 1 : 0) * kStep, bq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      // r and z from one reciprocal: with p = 1 + e^-a, q = 1 + e^-b and i = 1/(p q),
+      // r = q i and z = p i.  The exponents are clamped at 40 so that p q stays finite (a NaN
+      // pre-activation is dropped by fminf here and carried by the n gate, whose clamp keeps it).
+      const float ar = acc[0][e] + b_r;
+      const float az = acc[1][e] + b_z;
+      const float pr = 1.0f + __expf(fminf(-ar, 40.0f));
+      const float pz = 1.0f + __expf(fminf(-az, 40.0f));
+      const float inv = rcpf_(pr * pz);
+      const float r = pz * inv;
+      const float z = pr * inv;
+      const float hn = acc[3][e] + b_hn;
+      const float n = tanhf_(acc[2][e] + b_in + r * hn);
+      hy[e] = n + z * (hy[e] - n);
+    }
+    prev_row0 = row0;
+    tile = next;
+  };
+
+  body(std::true_type{});
+  while (tile < n_tiles) body(std::false_type{});
+  store_tile(prev_row0);
+}
+
+template <int KT>
+int launch(const GruRowsArgs& a, hipStream_t st) {
+  constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep;
+  static_assert(lds <= 160 * 1024, "weight slice does not fit LDS");
+  auto kern = a.x_bounded ? gru_rows_kernel<KT, true> : gru_rows_kernel<KT, false>;
+  static bool configured = false;
+  if (!configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rows_kernel<KT, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rows_kernel<KT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  // One workgroup per CU (the slice image takes most of its LDS); a small batch gets as many
+  // row groups as it has tiles for, in whole sets of 8 XCDs x NS slices.
+  constexpr int NS = KT / 2;
+  const int64_t n_tiles = (a.M + 31) / 32;
+  int64_t sets = (n_tiles + 63) / 64;  // a row group's workgroup has 8 waves, a set 8 groups
+  const int64_t max_sets = 256 / (8 * NS);
+  if (sets > max_sets) sets = max_sets;
+  kern<<<static_cast<unsigned>(sets * 8 * NS), 512, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("gru_rows");
+  return SPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmi_gru_rows_supported(int64_t I, int64_t H) { return I == 128 && H == 128; }
+
+int spmi_gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                      const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
+                      float* h_out, int x_bounded, void* stream) {
+  SPMI_REQUIRE(spmi_gru_rows_supported(I, H), SPMI_ERR_UNSUPPORTED,
+               "spmi_gru_rows_fwd: needs I = H = 128 (I=%lld H=%lld)", (long long)I, (long long)H);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gru_rows_fwd: bad M=%lld",
+               (long long)M);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(x && ws_ih && ws_hh && h_in && h_out && ldx >= I && ldx % 4 == 0, SPMI_ERR_INVALID_ARG,
+               "spmi_gru_rows_fwd: null pointer or bad ldx");
+  SPMI_REQUIRE(ldx < (int64_t{1} << 24), SPMI_ERR_UNSUPPORTED,
+               "spmi_gru_rows_fwd: leading dimension %lld too large", (long long)ldx);
+  for (const void* q : {(const void*)x, ws_ih, ws_hh, (const void*)h_in, (const void*)h_out})
+    SPMI_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15u) == 0, SPMI_ERR_INVALID_ARG,
+                 "spmi_gru_rows_fwd: pointers must be 16-byte aligned");
+  {
+    // every row is read by several workgroups and written in column slices: in place would
+    // hand some of them the new state
+    const uintptr_t i0 = reinterpret_cast<uintptr_t>(h_in), o0 = reinterpret_cast<uintptr_t>(h_out);
+    const uintptr_t bytes = static_cast<uintptr_t>(M) * H * sizeof(float);
+    SPMI_REQUIRE(i0 + bytes <= o0 || o0 + bytes <= i0, SPMI_ERR_INVALID_ARG,
+                 "spmi_gru_rows_fwd: h_out overlaps h_in");
+    const uintptr_t x0 = reinterpret_cast<uintptr_t>(x);
+    const uintptr_t xbytes = (static_cast<uintptr_t>(M - 1) * ldx + I) * sizeof(float);
+    SPMI_REQUIRE(x0 + xbytes <= o0 || o0 + bytes <= x0, SPMI_ERR_INVALID_ARG,
+                 "spmi_gru_rows_fwd: h_out overlaps x");
+  }
+  GruRowsArgs a{};
+  a.x = x; a.ldx = ldx;
+  a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
+  a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.h_out = h_out; a.M = M; a.x_bounded = x_bounded;
+  return launch<8>(a, spmi::as_stream(stream));
+}
+
+}  // extern "C"

@@ -43,6 +43,19 @@ class NodeMemory:
         """Fresh standard-normal state, drawn on the CPU generator like the reference
         (implicitTimeModels.py:46) so that a seeded run yields the same values."""
         self.memory = torch.randn(self.n_layers, self.n_nodes, self.hidden_d).to(self._device)
+        self._spare = None
+
+    def spare(self) -> torch.Tensor:
+        """A second table of the memory's shape and device (contents undefined), for steps
+        that write the new state of every node beside the old one."""
+        sp = getattr(self, "_spare", None)
+        if sp is None or sp.shape != self.memory.shape or sp.device != self.memory.device:
+            sp = self._spare = torch.empty_like(self.memory)
+        return sp
+
+    def swap_spare(self):
+        """The spare table holds the new state of every node: it becomes the memory."""
+        self.memory, self._spare = self._spare, self.memory
 
     def update_memory(self, new_memory: torch.Tensor, inx):
         self.memory[:, inx, :] = new_memory.to(self.memory.device)
@@ -61,6 +74,7 @@ class NodeMemory:
         ret = copy.copy(self)
         ret._device = device
         ret.memory = self.memory.to(device, **kwargs)
+        ret._spare = None
         return ret
 
 
@@ -175,8 +189,25 @@ class GRU(SequentialDecoder):
         self._check_base_model()
 
     def _step(self, x, ids):
+        mem = self.memory_h
+        # Every node, nothing tracked: the kernel that keeps the gate weights in LDS.  It
+        # cannot update rows in place, so the new state goes to the memory's second table and
+        # the two tables trade places afterwards; the returned rows are the new state itself.
+        whole = (ids is None and x.shape[0] == mem.memory.shape[1]
+                 and all(ops.gru_rows_ok(x if k == 0 else mem.memory[k], self._layer_params(k)[1])
+                         for k in range(self.n_layers))
+                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+        if whole:
+            new = mem.spare() if self.training_mode else None
+            for k in range(self.n_layers):
+                out = new[k] if new is not None else torch.empty_like(mem.memory[k])
+                x = ops.gru_rows(x, *self._layer_params(k), mem.memory[k], out, x_bounded=k > 0)
+                x = self._between_layers(x, k)
+            if new is not None:
+                mem.swap_spare()
+            return x
         for k in range(self.n_layers):
-            x = ops.gru_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,
+            x = ops.gru_cell(x, *self._layer_params(k), mem.memory[k], ids,
                              mem_write=self.training_mode, x_bounded=k > 0)  # layer k > 0 reads a cell's output
             x = self._between_layers(x, k)
         return x

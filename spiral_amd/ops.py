@@ -492,6 +492,9 @@ def _fused_ok(x, w_hh) -> bool:
 #               term (fp32-accurate over the whole fp32 range, twice the matrix work);
 #   "fp32"    = the fp32 matrix instruction (an exact fp32 FMA chain).
 CELL_GEMM = "f16x3"
+# Whole-table GRU steps (every node, inference) on the kernel that keeps the gate weights in
+# LDS and writes the new state to a second slab (csrc/cell_rows.hip).
+USE_GRU_ROWS = True
 
 
 def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
@@ -564,6 +567,35 @@ def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h
             nv.ptr(b_ih), nv.ptr(b_hh), nv.ptr(h_mem), nv.ptr(c_mem), nv.ptr(ids), x.shape[0],
             w_hh.shape[1], nv.ptr(h_out), nv.ptr(c_out), int(mem_write), nv.ptr(saved),
             nv.stream()), "spmi_cell_fused_fwd")
+
+
+def gru_rows_ok(x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+    """The whole-table GRU kernel takes this layer (csrc/cell_rows.hip): fp16-plane arithmetic
+    selected, shapes it is built for, nothing tracked for a backward pass."""
+    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and not (torch.is_grad_enabled() and (x.requires_grad or w_hh.requires_grad))
+            and bool(nv.lib().spmi_gru_rows_supported(x.shape[1], w_hh.shape[1])))
+
+
+def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out: torch.Tensor,
+             x_bounded: bool = False) -> torch.Tensor:
+    """One GRU layer step for every row: reads the state slab `h_in` [M, H], writes the new
+    state to `h_out` [M, H] (a different slab: the kernel cannot update in place) and returns
+    it.  Inference only (no gate values are kept)."""
+    _check_cell_args(x, h_in, None)
+    m, hd = x.shape[0], w_hh.shape[1]
+    if h_in.shape != (m, hd) or h_out.shape != (m, hd) or not h_out.is_contiguous() \
+            or h_out.dtype != torch.float32 or h_out.device != x.device:
+        raise nv.SpmiError("gru_rows: h_in and h_out must be contiguous float32 [M, H] slabs on x's device")
+    ws_ih, ws_hh = weight_planes(w_ih, "f16x3"), weight_planes(w_hh, "f16x3")
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().spmi_gru_rows_fwd(
+            nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+            nv.ptr(b_hh), nv.ptr(h_in), m, hd, nv.ptr(h_out), int(x_bounded), nv.stream()),
+            "spmi_gru_rows_fwd")
+    return h_out
 
 
 class GruCell(torch.autograd.Function):
