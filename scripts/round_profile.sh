@@ -1,0 +1,23 @@
+#!/bin/bash
+# One round profile: the default bench line, the same command under rocprofv3 --kernel-trace
+# --stats, the kernel timeline of one step, the other workloads, train mode and a two-rank
+# rehearsal of the multi-GPU path on one GPU.  usage: scripts/round_profile.sh <tag>
+set -e
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+tag=${1:-rXX}
+out=gpurun_out/$tag
+mkdir -p $out
+timeout -k 10 240 python3 bench.py > $out/bench_line.json 2> $out/bench.err
+echo "bench done"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline > $out/bench_profiled_line.json 2> $out/prof.err
+echo "profile done"
+python3 scripts/step_timeline.py $(ls $out/prof/*kernel_trace.csv | head -1) > $out/step_timeline.txt
+for w in config3 config4 config5 small; do
+  timeout -k 10 240 python3 bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_$w.json 2>> $out/bench.err
+  echo "$w done"
+done
+timeout -k 10 240 python3 bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_train.json 2>> $out/bench.err
+echo "train done"
+SPMI_BENCH_REHEARSE=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_rehearse2.json 2> $out/rehearse.err
+echo "rehearsal done"
