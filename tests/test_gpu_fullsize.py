@@ -142,3 +142,29 @@ def test_fused_gru_layer_at_full_size(big, dev):
     cpu = lambda t: t.detach().cpu().numpy()
     want = orc.gru_cell(cpu(x[rows]), cpu(mem0[rows]), cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
     assert np.abs(cpu(h_a[rows]) - want).max() < 1e-5
+
+
+def test_whole_table_gru_step_at_full_size(big, dev):
+    """The kernel that keeps the gate weights in LDS (spmi_gru_rows_fwd) over all nodes: equal
+    to the row-tile kernel on every row (same products, another summation order), equal to
+    the CPU oracle on a row sample that includes the first and the last tile, the old state
+    left untouched, and bit-identical when launched again."""
+    x = big["x"]
+    torch.manual_seed(2)
+    gru = torch.nn.GRU(F, F, batch_first=True).to(dev)
+    w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
+    mem0 = torch.randn(N, F, device=dev)
+    keep = mem0.clone()
+    with torch.no_grad():
+        assert ops.gru_rows_ok(x, w_hh)
+        h_a = ops.gru_rows(x, w_ih, w_hh, b_ih, b_hh, mem0, torch.empty_like(mem0))
+        h_a2 = ops.gru_rows(x, w_ih, w_hh, b_ih, b_hh, mem0, torch.empty_like(mem0))
+        h_b = ops.gru_cell(x, w_ih, w_hh, b_ih, b_hh, mem0.clone(), None, mem_write=False)
+    assert torch.equal(mem0, keep)
+    assert torch.equal(h_a, h_a2)
+    assert (h_a - h_b).abs().max() < 2e-6
+    pick = np.concatenate([np.arange(40), np.arange(N - 40, N), np.random.default_rng(3).integers(0, N, 4000)])
+    rows = torch.from_numpy(pick).to(dev)
+    cpu = lambda t: t.detach().cpu().numpy()
+    want = orc.gru_cell(cpu(x[rows]), cpu(keep[rows]), cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
+    assert np.abs(cpu(h_a[rows]) - want).max() < 1e-5
