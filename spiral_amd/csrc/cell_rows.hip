@@ -225,52 +225,69 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
 
-    // A row of x whose largest magnitude reaches 2^15 is multiplied by the power of two that
-    // brings it to [2^13, 2^14); its partial sums are scaled back before the state terms.
-    float up = 1.0f, down = 1.0f;
-    bool any_big = false;
-    if constexpr (!XB) {
-      float m = 0.0f;
+    // The x terms, optimistically unscaled: the K-steps start as their rows arrive, and the
+    // largest magnitude of every row is collected on the way (unless the caller vouches for it).
+    float m = 0.0f;
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
+    for (int t = 0; t < KT; ++t) {
+      if constexpr (!XB) {
         m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][0].x), fabsf(a[t][0].y)), fmaxf(fabsf(a[t][0].z), fabsf(a[t][0].w))));
         m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][1].x), fabsf(a[t][1].y)), fmaxf(fabsf(a[t][1].z), fabsf(a[t][1].w))));
       }
+      f16x8 p0, p1, p2;
+      split8<false>(a[t][0], a[t][1], 1.0f, p0, p1, p2);
+      if (t & 1) load_pair(hc, t >> 1);
+      // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
+      // the tile and then needs a second copy of the rows in registers.
+      __builtin_amdgcn_sched_barrier(0);
+      kstep_mfma<2>(acc, p0, p1, p2, sb + t * kStep, sb + (t + 1) * kStep, bq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // A row of x whose largest magnitude reaches 2^15 (count-valued features do) must not go
+    // through the fp16 planes as it is.  Rare, wave-uniform: the x terms of the whole tile are
+    // done again from memory, every such row multiplied by the power of two that brings it to
+    // [2^13, 2^14), and the partial sums are scaled back (exactly) before the state terms.
+    if constexpr (!XB) {
       m = fmaxf(m, __shfl_xor(m, 32));
       const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
       const bool big = ex >= 127 + 15 && ex != 255;                         // finite, >= 2^15
-      const int sh = big ? ex - (127 + 13) : 0;
-      up = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
-      down = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
-      any_big = __any(big);
-    }
-
-    auto x_phase = [&](auto scaled_tag) {
+      if (__any(big)) {
+        const int sh = big ? ex - (127 + 13) : 0;
+        const float up = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
+        const float down = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        f16x8 p0, p1, p2;
-        split8<decltype(scaled_tag)::value>(a[t][0], a[t][1], up, p0, p1, p2);
-        if (t & 1) load_pair(hc, t >> 1);
-        // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
-        // the tile and then needs a second copy of the rows in registers.
-        __builtin_amdgcn_sched_barrier(0);
-        kstep_mfma<2>(acc, p0, p1, p2, sb + t * kStep, sb + (t + 1) * kStep, bq);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    x_phase(std::integral_constant<bool, !XB>{});
-
-    if (any_big) {  // rare, wave-uniform
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ur = (e & 3) + 8 * (e >> 2);
-        // the inverse scale of row ur + 4 lh sits in lane ur + 4 lh (either half)
-        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
-        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
-        const float dn = lh ? d1 : d0;
-        acc[0][e] *= dn;
-        acc[1][e] *= dn;
-        acc[2][e] *= dn;
+          for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+        const float* xr = p.x + clamp_row(tile) * p.ldx + 16 * lh;
+        for (int t = 0; t < KT; ++t) {  // not unrolled: latency does not matter here, code size does
+          const float4* q4 = reinterpret_cast<const float4*>(xr + 32 * (t >> 1)) + 2 * (t & 1);
+          float4 lo = q4[0], hi = q4[1];
+          f16x8 p0, p1, p2;
+          split8<true>(lo, hi, up, p0, p1, p2);
+          const char* sf = sb + t * kStep;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const f16x8 w0 = *reinterpret_cast<const f16x8*>(sf + g * kGate);
+            const f16x8 w1 = *reinterpret_cast<const f16x8*>(sf + g * kGate + 1024);
+            const f16x8 w2 = *reinterpret_cast<const f16x8*>(sf + g * kGate + 2048);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, w1, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, w2, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, w0, acc[g], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ur = (e & 3) + 8 * (e >> 2);
+          // the inverse scale of row ur + 4 lh sits in lane ur + 4 lh (either half)
+          const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+          const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+          const float dn = lh ? d1 : d0;
+          acc[0][e] *= dn;
+          acc[1][e] *= dn;
+          acc[2][e] *= dn;
+        }
       }
     }
 
