@@ -150,3 +150,28 @@ def test_packed_head_layout():
     assert not ops.mlp_head_supported(128, [64, 1])                 # wider than the kernel holds
     assert not ops.mlp_head_supported(100, [10, 1])                 # input not a multiple of 32
     assert not ops.mlp_head_supported(1024, [32, 1])                # layer-1 weight beyond LDS budget
+
+
+def test_node_memory_spare_table_and_swap():
+    """The second table of a NodeMemory (used by steps that write every node's new state beside
+    the old one): same shape, created once, trades places with the memory on swap_spare(), and
+    is dropped by reset_state() and by a move to another device."""
+    import torch
+
+    from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder.implicitTimeModels import NodeMemory
+
+    mem = NodeMemory(7, 4, 2)
+    old = mem.memory
+    sp = mem.spare()
+    assert sp.shape == old.shape and sp.dtype == old.dtype and sp.data_ptr() != old.data_ptr()
+    assert mem.spare() is sp                                   # allocated once
+    sp.fill_(3.0)
+    mem.swap_spare()
+    assert mem.memory is sp and mem.spare() is old
+    assert torch.equal(mem.get_memory(torch.tensor([0, 6])), torch.full((2, 2, 4), 3.0))
+    mem.update_memory(torch.zeros(2, 2, 4), torch.tensor([1, 2]))
+    assert mem.memory[:, 1:3].abs().sum() == 0 and mem.memory[:, 0].eq(3.0).all()
+    mem.reset_state()
+    assert mem._spare is None and mem.memory.shape == (2, 7, 4)
+    moved = mem.to("meta")
+    assert moved._spare is None and moved.memory.device.type == "meta"
