@@ -336,32 +336,74 @@ __global__ void norm_from_degree_kernel(const int64_t* __restrict__ deg, int64_t
 }
 
 // ---- aggregation plan ---------------------------------------------------------------
-__global__ void plan_collect_kernel(const int32_t* __restrict__ indptr, int64_t N,
-                                    int32_t heavy_thresh, int32_t* __restrict__ heavy_rows,
-                                    int64_t capacity, int32_t* counts) {
-  int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r < N) {
-    int32_t deg = indptr[r + 1] - indptr[r];
-    if (deg > heavy_thresh) {
-      int32_t pos = atomicAdd(&counts[0], 1);
-      if (pos < capacity) heavy_rows[pos] = static_cast<int32_t>(r);
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanWaves = kPlanThreads / 64;
+constexpr int kPlanRows = 16;  // rows per thread of plan_collect_kernel
+
+// Exclusive scan of one value per thread over a 1024-thread workgroup (s_wave: kPlanWaves
+// entries; *total receives the workgroup sum).
+__device__ __forceinline__ uint32_t plan_block_scan(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+  const uint32_t incl = wave_inclusive_scan(v);
+  if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kPlanWaves; ++w) {
+    const uint32_t c = s_wave[w];
+    if (w < static_cast<int>(threadIdx.x >> 6)) base += c;
+    sum += c;
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// Lists the rows with more than heavy_thresh nonzeros.  A workgroup looks at 16384 rows,
+// compacts its hub rows among its threads and appends them with ONE atomic: with a threshold
+// of 128 a power-law snapshot of 1M rows has thousands of them, spread evenly, and an append
+// per row (or per wave, which is the same thing when they are 200 rows apart) queued 44 us
+// of atomics on one counter.  The list is in arrival order of the workgroups; results of the
+// aggregation do not depend on that order (each row is reduced on its own).
+__global__ __launch_bounds__(kPlanThreads) void plan_collect_kernel(
+    const int32_t* __restrict__ indptr, int64_t N, int32_t heavy_thresh,
+    int32_t* __restrict__ heavy_rows, int64_t capacity, int32_t* counts) {
+  __shared__ uint32_t s_wave[kPlanWaves];
+  __shared__ int32_t s_base;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (kPlanThreads * kPlanRows);
+  uint32_t flags = 0;
+#pragma unroll
+  for (int i = 0; i < kPlanRows; ++i) {
+    const int64_t r = row0 + i * kPlanThreads + threadIdx.x;
+    if (r < N && indptr[r + 1] - indptr[r] > heavy_thresh) flags |= 1u << i;
+  }
+  uint32_t total;
+  const uint32_t mine = static_cast<uint32_t>(__popc(flags));
+  const uint32_t ex = plan_block_scan(mine, s_wave, &total);
+  if (total == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&counts[0], static_cast<int32_t>(total));
+  __syncthreads();
+  int64_t pos = static_cast<int64_t>(s_base) + ex;
+#pragma unroll
+  for (int i = 0; i < kPlanRows; ++i) {
+    if (flags & (1u << i)) {
+      if (pos < capacity) heavy_rows[pos] = static_cast<int32_t>(row0 + i * kPlanThreads + threadIdx.x);
+      ++pos;
     }
   }
 }
 
 // Turns the collected list into chunk offsets: heavy_chunk_ptr = exclusive scan of
-// ceil(deg/chunk).  The list is in arrival order of the atomic append; results of
-// the aggregation do not depend on that order (each row is reduced on its own).
-__global__ __launch_bounds__(kThreads) void plan_finish_kernel(
+// ceil(deg/chunk) in list order.
+__global__ __launch_bounds__(kPlanThreads) void plan_finish_kernel(
     const int32_t* __restrict__ indptr, int32_t chunk, const int32_t* __restrict__ heavy_rows,
     int32_t* __restrict__ heavy_chunk_ptr, int64_t capacity, int32_t* counts) {
-  __shared__ uint32_t s_wave[kWaves];
+  __shared__ uint32_t s_wave[kPlanWaves];
   __shared__ uint32_t s_carry;
   const int64_t collected = counts[0];
   const int n = static_cast<int>(collected < capacity ? collected : capacity);
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += kThreads) {
+  for (int base = 0; base < n; base += kPlanThreads) {
     const int i = base + threadIdx.x;
     uint32_t c = 0;
     if (i < n) {
@@ -370,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void plan_finish_kernel(
       c = static_cast<uint32_t>((deg + chunk - 1) / chunk);
     }
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan(c, s_wave, &total);
+    const uint32_t ex = plan_block_scan(c, s_wave, &total);
     const uint32_t carry = s_carry;
     if (i < n) heavy_chunk_ptr[i] = static_cast<int32_t>(carry + ex);
     __syncthreads();
@@ -604,11 +646,12 @@ int spmi_spmm_plan(const int32_t* indptr, int64_t N, int32_t heavy_thresh, int32
   hipStream_t st = spmi::as_stream(stream);
   SPMI_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st));
   if (N > 0) {
-    plan_collect_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, heavy_thresh,
-                                                                heavy_rows, capacity - 1, counts);
+    const int64_t per_wg = kPlanThreads * kPlanRows;
+    plan_collect_kernel<<<(int)((N + per_wg - 1) / per_wg), kPlanThreads, 0, st>>>(
+        indptr, N, heavy_thresh, heavy_rows, capacity - 1, counts);
     SPMI_CHECK_LAUNCH("plan_collect");
   }
-  plan_finish_kernel<<<1, kThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr,
+  plan_finish_kernel<<<1, kPlanThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr,
                                              capacity - 1, counts);
   SPMI_CHECK_LAUNCH("plan_finish");
   return SPMI_OK;
