@@ -178,6 +178,25 @@ int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                      int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
                      void* stream);
 
+/* The aggregation of spmi_gcn_spmm_ex for callers that cannot allocate device memory or
+ * carry a workspace: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  The partial sums of the hub-row
+ * chunks go to an array built into the library (SPMI_STATIC_PARTIAL_FLOATS floats = 16 MiB,
+ * held by every GPU the library runs on until the process ends) instead of `partial_ws`;
+ * the call allocates and frees nothing and otherwise queues the same kernels, so results
+ * are bit-identical to spmi_gcn_spmm_ex.  n_chunks * F beyond SPMI_STATIC_PARTIAL_FLOATS
+ * is rejected with SPMI_ERR_WORKSPACE.  Every call on one GPU shares that GPU's array:
+ * two calls that overlap in time on one GPU (different streams or host threads) race;
+ * calls queued on one stream are safe. */
+#define SPMI_STATIC_PARTIAL_FLOATS (4 * 1024 * 1024)
+int spmi_gcn_spmm_static(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
+                         int64_t n_src, int64_t E, const void* X, int x_dtype, int64_t ldx,
+                         int64_t F, const float* src_scale, const float* edge_w,
+                         const float* dst_scale, const float* bias, int act, float slope, void* Y,
+                         int y_dtype, int64_t ldy, const int32_t* heavy_rows,
+                         const int32_t* heavy_chunk_ptr, int32_t n_heavy, int32_t n_chunks,
+                         int32_t heavy_thresh, int32_t chunk, void* stream);
+
 /* ------------------------------------------------------------------------
  * Backward of the fused epilogue: gP = gY * act'(Y) and gb = column sums.
  * Replaces the autograd of `rst + bias` / activation in GraphConv.forward.

@@ -9,6 +9,6 @@ char* error_buffer() {
 }  // namespace spmi
 
 extern "C" {
-int spmi_version(void) { return 100; }  // 0.1.0
+int spmi_version(void) { return 101; }  // 0.1.1
 const char* spmi_last_error(void) { return spmi::error_buffer(); }
 }

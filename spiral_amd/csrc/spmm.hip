@@ -22,6 +22,14 @@
 #include "common.h"
 
 #include <climits>
+#include <mutex>
+
+// Partial sums of hub-row chunks for spmi_gcn_spmm_static, the entry point for callers that
+// can neither allocate nor hand in a workspace.  Every GPU the library runs on holds its own
+// copy of this array, at its own address, until the process ends.  In host code the name is
+// only a handle for hipGetSymbolAddress: the device address it returns is what kernels,
+// memsets and copies take.
+static __device__ __align__(256) float scratch[SPMI_STATIC_PARTIAL_FLOATS];
 
 namespace {
 
@@ -463,6 +471,49 @@ int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                                         partial_ws, st);
   return dispatch_spmm<float, __bf16>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
                                       partial_ws, st);
+}
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices] = {nullptr};  // device address of `scratch`, per GPU
+}  // namespace
+
+int spmi_gcn_spmm_static(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
+                         int64_t n_src, int64_t E, const void* X, int x_dtype, int64_t ldx,
+                         int64_t F, const float* src_scale, const float* edge_w,
+                         const float* dst_scale, const float* bias, int act, float slope, void* Y,
+                         int y_dtype, int64_t ldy, const int32_t* heavy_rows,
+                         const int32_t* heavy_chunk_ptr, int32_t n_heavy, int32_t n_chunks,
+                         int32_t heavy_thresh, int32_t chunk, void* stream) {
+  SPMI_REQUIRE(n_heavy >= 0 && n_chunks >= n_heavy && F >= 1, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm_static: bad heavy plan (%d rows, %d chunks) or F=%lld", n_heavy,
+               n_chunks, (long long)F);
+  SPMI_REQUIRE(static_cast<int64_t>(n_chunks) * F <= int64_t{SPMI_STATIC_PARTIAL_FLOATS},
+               SPMI_ERR_WORKSPACE,
+               "spmi_gcn_spmm_static: %d hub-row chunks x %lld columns exceed the built-in scratch "
+               "of %lld floats; use spmi_gcn_spmm_ex with a workspace",
+               n_chunks, (long long)F, (long long)SPMI_STATIC_PARTIAL_FLOATS);
+  float* partial = nullptr;
+  if (n_heavy > 0) {
+    int dev = -1;
+    SPMI_CHECK_HIP(hipGetDevice(&dev));
+    SPMI_REQUIRE(dev >= 0 && dev < kMaxDevices, SPMI_ERR_UNSUPPORTED,
+                 "spmi_gcn_spmm_static: device ordinal %d beyond %d", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+      void* addr = nullptr;
+      SPMI_CHECK_HIP(hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch)));
+      SPMI_REQUIRE(addr != nullptr, SPMI_ERR_HIP, "spmi_gcn_spmm_static: scratch has no device address");
+      g_scratch_ptr[dev] = static_cast<float*>(addr);
+    }
+    partial = g_scratch_ptr[dev];
+  }
+  // Every chunk's partial row is written by spmm_heavy_kernel before spmm_heavy_reduce_kernel
+  // reads it, so nothing of the previous call's contents is ever read: no clearing needed.
+  return spmi_gcn_spmm_ex(indptr, indices, n_rows, n_src, E, X, x_dtype, ldx, F, src_scale, edge_w,
+                          dst_scale, bias, act, slope, Y, y_dtype, ldy, heavy_rows, heavy_chunk_ptr,
+                          n_heavy, n_chunks, heavy_thresh, chunk, partial, stream);
 }
 
 int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
