@@ -43,6 +43,7 @@ from spiral_amd import parallel as par  # noqa: E402
 from spiral_amd.core.types import GraphConv  # noqa: E402
 from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder.implicitTimeModels import GRU  # noqa: E402
 from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP  # noqa: E402
+from spiral_amd.dtdg.types import identity_ids  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -272,8 +273,7 @@ def main():
     model = Path(f, w["hidden"], w["rnn_hidden"], n_local, dev, kind)
     if kind == "evolve_bf16":
         x_local = x_local.to(torch.bfloat16)
-    ids = torch.arange(n_local, device=dev)
-    ids._spmi_identity = True
+    ids = identity_ids(n_local, dev)
     pipelined = world > 1 and args.mode == "forward" and args.exchange == "pipelined"
     payload = torch.bfloat16 if args.gather_dtype == "bf16" else None
     if pipelined:

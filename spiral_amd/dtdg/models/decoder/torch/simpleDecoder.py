@@ -8,9 +8,10 @@ import torch
 from torch import nn
 
 from spiral_amd.nn.linear import TallLinear
+from spiral_amd.ops import WeightCacheHooks, cache_epoch
 
 
-class SimpleDecoder(nn.Module):
+class SimpleDecoder(WeightCacheHooks, nn.Module):
     def __init__(self):
         super().__init__()
         self.layers = nn.ModuleList()
@@ -103,8 +104,9 @@ class MLP(SimpleDecoder):
             tensors = self._fold_tensors = [t for m in self.layers
                                             for t in list(m.parameters()) + list(m.buffers())]
         # one integer per call: in-place updates bump _version, re-assignment or a move to
-        # another device changes data_ptr
-        key = 0
+        # another device changes data_ptr; edits through .data change neither and need
+        # ops.invalidate_weight_caches(), which moves the epoch
+        key = cache_epoch()
         for t in tensors:
             key = key * 1000003 + t._version * 31 + t.data_ptr()
         cached = getattr(self, "_fold_cache", None)

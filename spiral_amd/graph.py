@@ -312,11 +312,12 @@ class NormalisedAdjacency:
         cache = self._edge_scale_cache()
         w = cache.get(key)
         if w is None and scaled:
-            csr = self.csr(wait=False) if direction == "fwd" else self.csr_t(wait=False)
+            # wait for the build's verdict first: after a failed range check `indices` holds
+            # unchecked or unwritten entries, which must not reach a gather
+            csr = self.csr() if direction == "fwd" else self.csr_t()
             w = cache[key] = self.norm(side, mode).index_select(0, csr.indices)
         if edge_weight is not None:
-            csr = (self.csr(want_eid=True, wait=False) if direction == "fwd"
-                   else self.csr_t(want_eid=True, wait=False))
+            csr = self.csr(want_eid=True) if direction == "fwd" else self.csr_t(want_eid=True)
             p = edge_weight.detach().to(torch.float32).reshape(-1).index_select(0, csr.eid)
             w = p if w is None else w * p
         return w

@@ -22,7 +22,7 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
-from spiral_amd.ops import gcn_aggregate, graphconv_inference, rows_times_weight
+from spiral_amd.ops import WeightCacheHooks, gcn_aggregate, graphconv_inference, rows_times_weight
 
 
 def _classify_activation(act) -> Tuple[Optional[str], float, Optional[Callable]]:
@@ -38,7 +38,7 @@ def _classify_activation(act) -> Tuple[Optional[str], float, Optional[Callable]]
     return None, 0.01, act
 
 
-class GraphConv(nn.Module):
+class GraphConv(WeightCacheHooks, nn.Module):
     def __init__(self, in_feats: int, out_feats: int, norm: str = "both", weight: bool = True,
                  bias: bool = True, activation=None, allow_zero_in_degree: bool = False):
         super().__init__()

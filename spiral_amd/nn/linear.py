@@ -6,10 +6,10 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from spiral_amd.ops import linear_rows
+from spiral_amd.ops import WeightCacheHooks, linear_rows
 
 
-class TallLinear(nn.Linear):
+class TallLinear(WeightCacheHooks, nn.Linear):
     def forward(self, input: torch.Tensor) -> torch.Tensor:  # noqa: A002 (torch's argument name)
         if input.is_cuda and input.dim() == 2 and input.dtype == torch.float32:
             return linear_rows(input, self.weight, self.bias)

@@ -161,7 +161,7 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
     mode = 0 if norm == "both" else 1
     scale = g.norm("out", mode) if norm in ("both", "left") else None
     rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale,
-                    planes=weight_planes(weight, "f16x3", True))
+                    planes=weight_planes(weight, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
     dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
     return aggregate(g.csr(wait=False), rst, None, None, dst_scale,
                      None if bias is None else bias.detach(), act, slope)
@@ -170,14 +170,14 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
 def _mm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ w (+ bias), w [K, N], no autograd."""
     if _gemm_rows_ok(x, w.shape[0], w.shape[1]):
-        return gemm_rows(x, w.detach().t(), bias, planes=weight_planes(w, "f16x3", True))
+        return gemm_rows(x, w.detach().t(), bias, planes=weight_planes(w, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
     return torch.addmm(bias, x, w) if bias is not None else x @ w
 
 
 def _mm_nk(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ weight.T (+ bias), weight [N, K], no autograd."""
     if _gemm_rows_ok(x, weight.shape[1], weight.shape[0]):
-        return gemm_rows(x, weight.detach(), bias, planes=weight_planes(weight, "f16x3"))
+        return gemm_rows(x, weight.detach(), bias, planes=weight_planes(weight, "f16x3", False, F16X3_GEMM_ROWS_LIMIT))
     return torch.nn.functional.linear(x, weight, bias)
 
 
@@ -526,20 +526,98 @@ def split_f16x3(w: torch.Tensor) -> torch.Tensor:
 # Operand planes of a weight are kept per tensor object for as long as the tensor is alive and
 # unchanged (same version counter, same storage address): an inference loop then launches no
 # split kernel and no transpose copy per call, a training loop re-splits after every update.
+#
+# What the key cannot see: an in-place edit made through `.data` (`p.data.mul_(..)`,
+# `p.data -= lr * g`) bumps no version counter and moves no storage.  Code that updates weights
+# that way calls `invalidate_weight_caches()` afterwards; the modules of this package call it
+# from `train()` / `eval()` and after `load_state_dict`.
 _plane_cache: dict = {}
+_cache_epoch = 0
+
+# |w| limits of the fp16-plane kernels: a weight beyond them turns into +-inf in its first
+# plane and every output row into inf/NaN.
+F16X3_CELL_LIMIT = 65504.0
+F16X3_GEMM_ROWS_LIMIT = 1023.0
 
 
-def weight_planes(w: torch.Tensor, kind: str = "f16x3", transposed: bool = False) -> torch.Tensor:
-    """`split_f16x3` / `split_bf16x3` of `w` (of `w.T` when `transposed`), cached."""
+def invalidate_weight_caches() -> None:
+    """Forget every cached operand image of a weight (the fp16/bf16 planes of the dense
+    kernels, the folded and packed layers of the one-kernel MLP head): the next use rebuilds
+    them from the weights as they are then.  Needed after edits the cache keys cannot see,
+    i.e. in-place changes through `.data`."""
+    global _cache_epoch
+    _cache_epoch += 1
+    _plane_cache.clear()
+
+
+def cache_epoch() -> int:
+    return _cache_epoch
+
+
+class WeightCacheHooks:
+    """Mixin for the modules whose inference kernels read cached operand images of their
+    weights: switching between train() and eval() and loading a state dict drop the images, so
+    that a weight edited through `.data` in between (an optimiser written by hand, a restored
+    checkpoint) is never multiplied in its old form."""
+
+    def train(self, mode: bool = True):
+        invalidate_weight_caches()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # runs for this module also when a parent's load_state_dict recurses into it
+        super()._load_from_state_dict(*args, **kwargs)
+        invalidate_weight_caches()
+
+
+class _DomainCheck:
+    """max |w| of a weight on its way to pinned host memory, so that the domain check of the
+    fp16-plane kernels never makes the host wait for the device: the value is looked at the
+    first time the planes are used again after the copy has landed."""
+
+    def __init__(self, src: torch.Tensor, limit: float):
+        self.limit = limit
+        self.host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        self.host.copy_(torch.linalg.vector_norm(src.float(), ord=float("inf")).reshape(1), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def done(self, wait: bool = False) -> bool:
+        if wait:
+            self.event.synchronize()
+        elif not self.event.query():
+            return False
+        amax = float(self.host[0])
+        if not amax <= self.limit:
+            raise nv.SpmiError(
+                f"a weight of magnitude {amax:g} is outside the fp16-plane kernels' domain "
+                f"(|w| <= {self.limit:g}): results computed from it are inf/NaN; set "
+                "ops.CELL_GEMM = 'bf16x3' or 'fp32' / ops.DENSE_GEMM = 'library' for this model")
+        return True
+
+
+def weight_planes(w: torch.Tensor, kind: str = "f16x3", transposed: bool = False,
+                  limit: Optional[float] = None) -> torch.Tensor:
+    """`split_f16x3` / `split_bf16x3` of `w` (of `w.T` when `transposed`), cached.  `limit`: the
+    largest |w| the consuming kernel takes.  It is checked whenever planes are (re)built, without
+    a host wait: the maximum travels to the host behind the split and is read at a later use of
+    the same weight (or when its planes are rebuilt), where an out-of-domain weight raises."""
     slot_id = (id(w), kind, transposed)
     key = (w._version, w.data_ptr(), tuple(w.shape), w.stride(), w.device)
     slot = _plane_cache.get(slot_id)
-    if slot is not None and slot[0]() is w and slot[1] == key:
-        return slot[2]
+    if slot is not None and slot[0]() is w:
+        if slot[3] is not None and slot[3].done(wait=slot[1] != key):
+            slot = _plane_cache[slot_id] = slot[:3] + (None,)
+        if slot[1] == key:
+            return slot[2]
     src = w.detach().t() if transposed else w.detach()
     planes = split_f16x3(src) if kind == "f16x3" else split_bf16x3(src)
+    check = None
+    if limit is not None and kind == "f16x3" and src.numel():
+        with torch.cuda.device(w.device):
+            check = _DomainCheck(src, limit)
     ref = weakref.ref(w, lambda _r, k=slot_id: _plane_cache.pop(k, None))
-    _plane_cache[slot_id] = (ref, key, planes)
+    _plane_cache[slot_id] = (ref, key, planes, check)
     return planes
 
 
@@ -548,7 +626,8 @@ def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h
     csrc/cell_fused.hip, see CELL_GEMM)."""
     if CELL_GEMM in ("bf16x3", "f16x3"):
         name = "spmi_cell_split_fwd" if CELL_GEMM == "bf16x3" else "spmi_cell_f16x3_fwd"
-        ws_ih, ws_hh = weight_planes(w_ih, CELL_GEMM), weight_planes(w_hh, CELL_GEMM)
+        ws_ih = weight_planes(w_ih, CELL_GEMM, False, F16X3_CELL_LIMIT)
+        ws_hh = weight_planes(w_hh, CELL_GEMM, False, F16X3_CELL_LIMIT)
         with torch.cuda.device(x.device):
             nv.check(getattr(nv.lib(), name)(
                 _CELL_CODE[kind], nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh),
@@ -569,13 +648,16 @@ def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h
             nv.stream()), "spmi_cell_fused_fwd")
 
 
-def gru_rows_ok(x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+def gru_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
     """The whole-table GRU kernel takes this layer (csrc/cell_rows.hip): fp16-plane arithmetic
-    selected, shapes it is built for, nothing tracked for a backward pass."""
+    selected, shapes it is built for, nothing tracked for a backward pass.  `params`: the
+    layer's other parameters (w_ih, b_ih, b_hh); the kernel keeps no graph, so one trainable
+    tensor among them under grad mode sends the layer to the tracked cell instead."""
+    tracked = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
     return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
-            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-            and not (torch.is_grad_enabled() and (x.requires_grad or w_hh.requires_grad))
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
             and bool(nv.lib().spmi_gru_rows_supported(x.shape[1], w_hh.shape[1])))
 
 
@@ -589,7 +671,8 @@ def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
     if h_in.shape != (m, hd) or h_out.shape != (m, hd) or not h_out.is_contiguous() \
             or h_out.dtype != torch.float32 or h_out.device != x.device:
         raise nv.SpmiError("gru_rows: h_in and h_out must be contiguous float32 [M, H] slabs on x's device")
-    ws_ih, ws_hh = weight_planes(w_ih, "f16x3"), weight_planes(w_hh, "f16x3")
+    ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
+    ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)
     with torch.cuda.device(x.device):
         nv.check(nv.lib().spmi_gru_rows_fwd(
             nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),

@@ -182,3 +182,42 @@ def test_weight_planes_cache_follows_the_weight(dev):
     import gc
     gc.collect()
     assert len(ops._plane_cache) < n_before                           # entries die with the tensor
+
+
+def test_edits_through_dot_data_need_an_explicit_invalidation(dev):
+    """`.data` edits bump no version counter and move no storage, so the cached planes cannot
+    notice them; `ops.invalidate_weight_caches()` (also called by train()/eval() and after
+    load_state_dict of the package's modules) makes the next call re-split the weight."""
+    from spiral_amd.nn.linear import TallLinear
+
+    lin = TallLinear(64, 64, bias=False).to(dev)
+    x = torch.randn(4096, 64, device=dev)
+    with torch.no_grad():
+        y1 = lin(x)
+        lin.weight.data.mul_(2.0)
+        ops.invalidate_weight_caches()
+        y2 = lin(x)
+        assert torch.allclose(y2, 2.0 * y1, rtol=1e-5, atol=1e-6)
+        lin.weight.data.mul_(0.5)
+        lin.eval()                                   # the module hook drops the planes as well
+        y3 = lin(x)
+        assert torch.allclose(y3, y1, rtol=1e-5, atol=1e-6)
+        state = {k: v * 3.0 for k, v in lin.state_dict().items()}
+        outer = torch.nn.Sequential(lin)
+        outer.load_state_dict({"0." + k: v for k, v in state.items()})
+        y4 = lin(x)
+        assert torch.allclose(y4, 3.0 * y1, rtol=1e-5, atol=1e-5)
+
+
+def test_weight_beyond_the_fp16_plane_domain_is_reported(dev):
+    """|W| > 1023 makes spmi_gemm_rows return inf/NaN; the cached planes remember the weight's
+    magnitude and a later use raises instead of going on with such results."""
+    w = torch.nn.Parameter(torch.randn(64, 64, device=dev))
+    with torch.no_grad():
+        w[3, 5] = 5000.0
+    x = torch.randn(4096, 64, device=dev)
+    with torch.no_grad():
+        ops.rows_times_weight(x, w)
+        torch.cuda.synchronize()
+        with pytest.raises(nv.SpmiError, match="domain"):
+            ops.rows_times_weight(x, w)

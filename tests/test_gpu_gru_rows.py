@@ -122,7 +122,6 @@ def test_decoder_trades_memory_tables(dev):
     dec.eval()                                            # BatchNorm on running statistics
     start = dec.memory_h.memory.clone()
     ids = torch.arange(n, device=dev)
-    ids._spmi_identity = True
     xs = [torch.randn(n, 128, device=dev) for _ in range(3)]
 
     def run(flag):

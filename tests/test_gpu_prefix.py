@@ -122,3 +122,26 @@ def test_citation_feature_from_the_table_grouping(dev):
         assert torch.equal(fa, fb)
         want = orc.citation_dispatch(edges, nodes, len(ts), t)[3]
         np.testing.assert_array_equal(fa.cpu().numpy(), want)
+
+
+def test_bad_prefix_raises_before_any_gather_in_the_tracked_layer(dev):
+    """A snapshot whose edges run ahead of its nodes: the prefix cut reports it through its
+    status word and leaves part of `indices` unwritten.  The grad-enabled GraphConv builds a
+    per-edge weight by gathering with those indices, so it must collect the verdict first and
+    raise SpmiError instead of reading out of range."""
+    from spiral_amd.core.types import GraphConv
+
+    edges = np.array([[0, 1, 0], [0, 2, 1], [0, 7, 2], [1, 3, 1], [1, 8, 0]], dtype=np.float64)
+    nodes = np.concatenate([np.array([0, 0, 0, 1, 1, 1, 1, 1, 1, 1])[:, None].astype(np.float64),
+                            np.random.default_rng(0).standard_normal((10, 4))], axis=1)
+    graph = VEInvariantDTDG(edges, nodes, np.arange(2), device=dev)
+    snap, _ = graph.dispatcher(0)                       # 3 nodes, but an edge from node 7
+    conv = GraphConv(4, 4, allow_zero_in_degree=True).to(dev)
+    x = snap.node_feature().clone().requires_grad_(True)
+    with pytest.raises(nv.SpmiError):
+        conv(snap.observation, x)
+    with torch.no_grad(), pytest.raises(nv.SpmiError):  # the inference path as well
+        conv(graph.dispatcher(0)[0].observation, x.detach())
+    good, _ = graph.dispatcher(1)
+    out = conv(good.observation, good.node_feature())   # the table itself is fine
+    assert out.shape == (10, 4) and bool(torch.isfinite(out).all())
