@@ -1,4 +1,7 @@
-"""The path at the full size of the headline workload (1M nodes, 10M edges, 128 features),
+"""The path at the full size of three BASELINE workloads -- config2 (1M nodes, 10M edges,
+128 features; the headline), config3 (10M nodes, 100M edges, 128 features: the single-GPU
+instance of the row-partitioned workload) and config5 (1M nodes, 10M edges, 256 features,
+heavy degree skew k_dst = 6: the per-GPU size of the wide-feature stress) --
 where the CPU oracle cannot check every output in seconds: structural invariants of the CSR,
 size-independent algebraic properties of the aggregation (linearity, column checksums,
 adjointness of forward and backward), an independent library SpMM, determinism, and the
@@ -14,28 +17,35 @@ from spiral_amd import ops
 
 pytestmark = pytest.mark.gpu
 
-N, E, F = 1_000_000, 10_000_000, 128
+SIZES = {  # nodes, edges, features, k_dst
+    "config2": (1_000_000, 10_000_000, 128, 3.0),
+    "config3": (10_000_000, 100_000_000, 128, 3.0),
+    "config5": (1_000_000, 10_000_000, 256, 6.0),
+}
 
 
-@pytest.fixture(scope="module")
-def big(dev):
+@pytest.fixture(scope="module", params=list(SIZES))
+def big(request, dev):
+    n, e, f, k_dst = SIZES[request.param]
     gen = torch.Generator(device=dev)
     gen.manual_seed(99)
-    perm = torch.randperm(N, generator=gen, device=dev)
+    perm = torch.randperm(n, generator=gen, device=dev)
     gen.manual_seed(1234)
-    u1 = torch.rand(E, generator=gen, device=dev, dtype=torch.float64)
-    u2 = torch.rand(E, generator=gen, device=dev, dtype=torch.float64)
-    dst = perm[(u1.pow_(3.0) * N).long().clamp_(max=N - 1)]
-    src = perm[(u2.pow_(1.5) * N).long().clamp_(max=N - 1)]
+    u1 = torch.rand(e, generator=gen, device=dev, dtype=torch.float64)
+    u2 = torch.rand(e, generator=gen, device=dev, dtype=torch.float64)
+    dst = perm[(u1.pow_(k_dst) * n).long().clamp_(max=n - 1)]
+    src = perm[(u2.pow_(1.5) * n).long().clamp_(max=n - 1)]
+    del u1, u2
     gen.manual_seed(7)
-    x = torch.randn(N, F, generator=gen, device=dev)
-    g = G.SnapshotGraph(src, dst, N)
-    yield dict(src=src, dst=dst, x=x, g=g)
+    x = torch.randn(n, f, generator=gen, device=dev)
+    g = G.SnapshotGraph(src, dst, n)
+    yield dict(src=src, dst=dst, x=x, g=g, n=n, e=e, f=f, name=request.param)
+    del g, x, src, dst
     torch.cuda.empty_cache()
 
 
 def test_csr_invariants_at_full_size(big):
-    src, dst, g = big["src"], big["dst"], big["g"]
+    src, dst, g, N, E = big["src"], big["dst"], big["g"], big["n"], big["e"]
     for key, other, csr in ((dst, src, g.csr(want_eid=True)), (src, dst, g.csr_t(want_eid=True))):
         indptr, eid = csr.indptr.long(), csr.eid.long()
         assert indptr[0] == 0 and indptr[-1] == E
@@ -54,7 +64,7 @@ def test_csr_invariants_at_full_size(big):
 
 
 def test_aggregation_properties_at_full_size(big):
-    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    src, dst, x, g, N = big["src"], big["dst"], big["x"], big["g"], big["n"]
     with torch.no_grad():
         y = ops.gcn_aggregate(g, x, "both")
         # determinism: the launch is reproducible bit for bit
@@ -86,7 +96,7 @@ def test_aggregation_properties_at_full_size(big):
 
 def test_aggregation_against_library_spmm_at_full_size(big):
     """hipSPARSE through torch.sparse is an independent implementation of the same sum."""
-    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    src, dst, x, g, N, E = big["src"], big["dst"], big["x"], big["g"], big["n"], big["e"]
     csr = g.csr()
     with torch.no_grad():
         y = ops.gcn_aggregate(g, x, "none")
@@ -97,7 +107,7 @@ def test_aggregation_against_library_spmm_at_full_size(big):
 
 
 def test_sampled_rows_against_the_oracle_at_full_size(big):
-    src, dst, x, g = big["src"], big["dst"], big["x"], big["g"]
+    src, dst, x, g, N, F = big["src"], big["dst"], big["x"], big["g"], big["n"], big["f"]
     rng = np.random.default_rng(0)
     deg = g.in_degrees()
     hubs = torch.topk(deg, 3).indices.cpu().numpy()                 # chunked hub-row path
@@ -123,7 +133,9 @@ def test_sampled_rows_against_the_oracle_at_full_size(big):
 def test_fused_gru_layer_at_full_size(big, dev):
     """One recurrent layer over all nodes: the one-kernel path equals the library-GEMM +
     gate-kernel path, and a row sample equals the CPU oracle (rows are independent)."""
-    x = big["x"]
+    if big["name"] != "config2":
+        pytest.skip("the recurrent layer does not depend on the graph: run once, at the headline size")
+    x, N, F = big["x"], big["n"], big["f"]
     torch.manual_seed(2)
     gru = torch.nn.GRU(F, F, batch_first=True).to(dev)
     w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
@@ -149,7 +161,9 @@ def test_whole_table_gru_step_at_full_size(big, dev):
     to the row-tile kernel on every row (same products, another summation order), equal to
     the CPU oracle on a row sample that includes the first and the last tile, the old state
     left untouched, and bit-identical when launched again."""
-    x = big["x"]
+    if big["name"] != "config2":
+        pytest.skip("the recurrent layer does not depend on the graph: run once, at the headline size")
+    x, N, F = big["x"], big["n"], big["f"]
     torch.manual_seed(2)
     gru = torch.nn.GRU(F, F, batch_first=True).to(dev)
     w_ih, w_hh, b_ih, b_hh = gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0
@@ -168,3 +182,34 @@ def test_whole_table_gru_step_at_full_size(big, dev):
     cpu = lambda t: t.detach().cpu().numpy()
     want = orc.gru_cell(cpu(x[rows]), cpu(keep[rows]), cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
     assert np.abs(cpu(h_a[rows]) - want).max() < 1e-5
+
+
+def test_graphconv_layer_at_full_size(big, dev):
+    """The whole layer as the benchmark runs it (no_grad; 128 -> 128 multiplies first,
+    256 -> 512 aggregates first as DGL does for in_feats < out_feats): a sample of rows plus
+    the largest hubs against a float64 evaluation from the edge list."""
+    from spiral_amd.core.types import GraphConv
+
+    src, dst, x, g, N, F = big["src"], big["dst"], big["x"], big["g"], big["n"], big["f"]
+    fo = 512 if F == 256 else 128
+    torch.manual_seed(4)
+    conv = GraphConv(F, fo, activation=torch.nn.functional.leaky_relu, allow_zero_in_degree=True).to(dev)
+    with torch.no_grad():
+        conv.bias.normal_()
+        y = conv(g, x)
+    deg = g.in_degrees()
+    rows = torch.unique(torch.cat([torch.topk(deg, 3).indices,
+                                   torch.randint(0, N, (2000,), generator=torch.Generator().manual_seed(1)).to(dev)]))
+    keep = torch.isin(dst, rows)
+    s_k, d_k = src[keep], dst[keep]
+    n_in = deg.double().clamp(min=1).rsqrt()
+    n_out = torch.bincount(src, minlength=N).double().clamp(min=1).rsqrt()
+    local = torch.searchsorted(rows, d_k)
+    msg = x[s_k].double() * n_out[s_k][:, None]
+    agg = torch.zeros(rows.numel(), F, dtype=torch.float64, device=dev).index_add_(0, local, msg)
+    mag = torch.zeros(rows.numel(), F, dtype=torch.float64, device=dev).index_add_(0, local, msg.abs())
+    w = conv.weight.double()
+    pre = (agg @ w) * n_in[rows][:, None] + conv.bias.double()
+    want = torch.where(pre > 0, pre, pre * 0.01)
+    scale = (mag @ w.abs()) * n_in[rows][:, None] + conv.bias.double().abs()
+    assert float(((y[rows].double() - want).abs() / scale.clamp_min(1e-30)).max()) < 1e-5

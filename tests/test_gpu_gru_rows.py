@@ -1,6 +1,6 @@
 """The whole-table GRU layer step (spmi_gru_rows_fwd, csrc/cell_rows.hip): gate weights of a
 32-unit column slice resident in LDS, rows streamed past them, new state written to a second
-slab.  Checked against the CPU oracle (1e-5 absolute on outputs bounded by 1: the fp32 bar of
+slab.  Checked against the CPU oracle (1e-5 relative to the largest entry of the expected state: the fp32 bar of
 the other recurrent kernels), against spmi_cell_f16x3_fwd, which computes the same sums in a
 different instruction order, and through the decoder, whose node memory trades tables."""
 import numpy as np
@@ -39,7 +39,7 @@ def test_against_oracle_and_the_row_tile_kernel(dev, m, bias):
     zeros = np.zeros(3 * 128, np.float32)
     want = orc.gru_cell(cpu(x), cpu(h0), cpu(w_ih), cpu(w_hh), cpu(b_ih) if bias else zeros,
                         cpu(b_hh) if bias else zeros)
-    assert np.abs(cpu(out) - want).max() < 1e-5
+    assert np.abs(cpu(out) - want).max() < 1e-5 * np.abs(want).max()
     with torch.no_grad():
         old, ops.CELL_GEMM = ops.CELL_GEMM, "f16x3"
         try:
@@ -59,7 +59,7 @@ def test_strided_x_and_padding_untouched(dev):
     slab = torch.full((m + 2, 128), 7.0, device=dev)
     ops.gru_rows(x, w_ih, w_hh, b_ih, b_hh, h0, slab[1:-1])
     want = orc.gru_cell(cpu(x), cpu(h0), cpu(w_ih), cpu(w_hh), cpu(b_ih), cpu(b_hh))
-    assert np.abs(cpu(slab[1:-1]) - want).max() < 1e-5
+    assert np.abs(cpu(slab[1:-1]) - want).max() < 1e-5 * np.abs(want).max()
     assert (slab[0] == 7.0).all() and (slab[-1] == 7.0).all()
 
 
@@ -89,12 +89,12 @@ def test_rows_of_x_of_any_magnitude(dev):
     want = (n + z * (h0.double() - n)).numpy()
     args = [t.to(dev) for t in (x, w_ih, w_hh, b_ih, b_hh, h0)]
     out = ops.gru_rows(*args, torch.empty(m, 128, device=dev))
-    assert np.abs(cpu(out) - want).max() < 1e-5
+    assert np.abs(cpu(out) - want).max() < 1e-5 * np.abs(want).max()
     bad = cpu(ops.gru_rows(*args, torch.empty(m, 128, device=dev), x_bounded=True))
     for row in (8, 9, 200, 299):                         # past fp16's range: inf planes
         assert not np.isfinite(bad[row]).all()
     rest = np.setdiff1d(np.arange(m), big_rows)
-    assert np.abs(bad[rest] - want[rest]).max() < 1e-5
+    assert np.abs(bad[rest] - want[rest]).max() < 1e-5 * np.abs(want[rest]).max()
 
 
 def test_overlap_and_shapes_are_rejected(dev):

@@ -87,7 +87,6 @@ def test_training_loop_matches_cpu_restatement(dev, kind):
         label = nxt.node_feature()[: snap.num_nodes(), -1].float()
         loss = F.mse_loss(predict.squeeze(), label)
         loss.backward()
-        opt.step()
         losses.append(loss.item())
 
         src, dst, n, feat, _ = orc.citation_dispatch(edges, nodes, steps, t)
@@ -96,6 +95,13 @@ def test_training_loop_matches_cpu_restatement(dev, kind):
         p_ref = ref.forward(src, dst, n, feat)
         loss_ref = F.mse_loss(p_ref.squeeze(), torch.from_numpy(feat_next[:n, -1]))
         loss_ref.backward()
+        if t == 2:  # identical parameters and state: every gradient at the fp32 bar
+            mine = [p for l in model.encoder.layers for p in (l.weight, l.bias)] + \
+                list(model.decoder.base_model.parameters()) + list(model.decoder.simple_decoder.parameters())
+            from tests.test_gpu_reference_loop import _check_first_step_gradients
+
+            _check_first_step_gradients(mine, ref.params, ref.mlp)
+        opt.step()
         opt_ref.step()
         losses_ref.append(loss_ref.item())
     assert abs(losses[0] - losses_ref[0]) / abs(losses_ref[0]) < 1e-5
