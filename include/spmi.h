@@ -178,6 +178,24 @@ int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                      int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
                      void* stream);
 
+/* The aggregation of spmi_gcn_spmm_ex in pieces, for a destination block whose source rows
+ * arrive in several batches (the row-partitioned layer: the sum over the sources of batch k
+ * runs while batch k+1 is still on the wire).  Each call covers the CSR of one batch of
+ * sources.  accumulate != 0: the sums are added to what Y already holds (the raw partial
+ * sums of the earlier calls); finalize == 0: Y receives the raw sums, without dst_scale,
+ * bias and activation, which only the last call (finalize != 0) applies.  Partial sums
+ * are float32: accumulate or finalize == 0 require y_dtype = SPMI_DTYPE_F32.  With
+ * accumulate = 0 and finalize = 1 this is spmi_gcn_spmm_ex.  Same reference lines (the
+ * update_all(copy_u, sum) of dgl GraphConv.forward); the reference has no partitioned
+ * form. */
+int spmi_gcn_spmm_part(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                       int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
+                       const float* src_scale, const float* edge_w, const float* dst_scale,
+                       const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
+                       const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
+                       int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
+                       int accumulate, int finalize, void* stream);
+
 /* The aggregation of spmi_gcn_spmm_ex for callers that cannot allocate device memory or
  * carry a workspace: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  No counterpart in the reference.  The partial sums of the hub-row

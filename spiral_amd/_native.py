@@ -40,6 +40,9 @@ _SIGNATURES = {
     "spmi_gcn_spmm_ex": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_i64, c_vp,
                                  c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_int, c_i64, c_vp, c_vp,
                                  c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "spmi_gcn_spmm_part": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_i64, c_vp,
+                                   c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_int, c_i64, c_vp, c_vp,
+                                   c_i32, c_i32, c_i32, c_i32, c_vp, c_int, c_int, c_vp]),
     "spmi_gcn_spmm_static": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_int, c_i64, c_i64, c_vp,
                                      c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_int, c_i64, c_vp, c_vp,
                                      c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -113,6 +113,8 @@ struct SpmmParams {
   int32_t act;
   float slope;
   int32_t heavy_thresh;
+  int32_t accumulate;  // add the sums to what Y holds (float32 Y only)
+  int32_t finalize;    // apply dst_scale, bias and activation; 0 = store the raw sums
 };
 
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -216,9 +218,16 @@ __global__ __launch_bounds__(kThreads) void spmm_stream_kernel(SpmmParams p) {
   YT* ycol = static_cast<YT*>(p.Y) + f;
   auto row_end_of = [&](int row) { return readlane_i(ip, row + 1); };
   auto flush = [&](int row, V acc) {
-    const float ds = readlane_f(dsl, row);
-    V y = activate<VEC>(acc * ds + bias, p.act, p.slope);
-    if (fok) store_row<VEC, YT>(ycol + static_cast<int64_t>(r0 + row) * p.ldy, y);
+    YT* yp = ycol + static_cast<int64_t>(r0 + row) * p.ldy;
+    if constexpr (sizeof(YT) == 4) {
+      if (p.accumulate && fok) acc += *reinterpret_cast<const V*>(yp);
+    }
+    V y = acc;
+    if (p.finalize) {
+      const float ds = readlane_f(dsl, row);
+      y = activate<VEC>(acc * ds + bias, p.act, p.slope);
+    }
+    if (fok) store_row<VEC, YT>(yp, y);
   };
 
   if (!any_heavy) {
@@ -316,11 +325,18 @@ __global__ __launch_bounds__(kThreads) void spmm_heavy_reduce_kernel(
     V sum = s_part[0][lane];
 #pragma unroll
     for (int w = 1; w < kWavesPerBlock; ++w) sum += s_part[w][lane];
-    const float ds = p.dst_scale ? p.dst_scale[row] : 1.0f;
-    V bias = V(0.0f);
-    if (p.bias) bias = *reinterpret_cast<const V*>(p.bias + f);
-    V y = activate<VEC>(sum * ds + bias, p.act, p.slope);
-    store_row<VEC, YT>(static_cast<YT*>(p.Y) + static_cast<int64_t>(row) * p.ldy + f, y);
+    YT* yp = static_cast<YT*>(p.Y) + static_cast<int64_t>(row) * p.ldy + f;
+    if constexpr (sizeof(YT) == 4) {
+      if (p.accumulate) sum += *reinterpret_cast<const V*>(yp);
+    }
+    V y = sum;
+    if (p.finalize) {
+      const float ds = p.dst_scale ? p.dst_scale[row] : 1.0f;
+      V bias = V(0.0f);
+      if (p.bias) bias = *reinterpret_cast<const V*>(p.bias + f);
+      y = activate<VEC>(sum * ds + bias, p.act, p.slope);
+    }
+    store_row<VEC, YT>(yp, y);
   }
 }
 
@@ -406,13 +422,15 @@ int dispatch_spmm(SpmmParams& p, const int32_t* heavy_rows, const int32_t* heavy
 
 extern "C" {
 
-int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
-                     int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
-                     const float* src_scale, const float* edge_w, const float* dst_scale,
-                     const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
-                     const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
-                     int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
-                     void* stream) {
+int spmi_gcn_spmm_part(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                       int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
+                       const float* src_scale, const float* edge_w, const float* dst_scale,
+                       const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
+                       const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
+                       int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
+                       int accumulate, int finalize, void* stream) {
+  SPMI_REQUIRE((!accumulate && finalize) || y_dtype == SPMI_DTYPE_F32, SPMI_ERR_INVALID_ARG,
+               "spmi_gcn_spmm_part: partial sums (accumulate / no finalize) need a float32 Y");
   SPMI_REQUIRE(n_rows >= 0 && n_src >= 0 && E >= 0 && F >= 1, SPMI_ERR_INVALID_ARG,
                "spmi_gcn_spmm: bad sizes n_rows=%lld n_src=%lld E=%lld F=%lld", (long long)n_rows,
                (long long)n_src, (long long)E, (long long)F);
@@ -453,6 +471,8 @@ int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_ro
   p.act = act;
   p.slope = slope;
   p.heavy_thresh = (n_heavy > 0) ? heavy_thresh : INT_MAX;
+  p.accumulate = accumulate != 0;
+  p.finalize = finalize != 0;
   // about 96 nonzeros per wave keeps the index load and the row stream busy
   const int64_t avg_deg = (E + n_rows - 1) / n_rows;
   int rpw = 32;
@@ -471,6 +491,19 @@ int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_ro
                                         partial_ws, st);
   return dispatch_spmm<float, __bf16>(p, heavy_rows, heavy_chunk_ptr, n_heavy, n_chunks, chunk,
                                       partial_ws, st);
+}
+
+int spmi_gcn_spmm_ex(const int32_t* indptr, const int32_t* indices, int64_t n_rows, int64_t n_src,
+                     int64_t E, const void* X, int x_dtype, int64_t ldx, int64_t F,
+                     const float* src_scale, const float* edge_w, const float* dst_scale,
+                     const float* bias, int act, float slope, void* Y, int y_dtype, int64_t ldy,
+                     const int32_t* heavy_rows, const int32_t* heavy_chunk_ptr, int32_t n_heavy,
+                     int32_t n_chunks, int32_t heavy_thresh, int32_t chunk, float* partial_ws,
+                     void* stream) {
+  return spmi_gcn_spmm_part(indptr, indices, n_rows, n_src, E, X, x_dtype, ldx, F, src_scale, edge_w,
+                            dst_scale, bias, act, slope, Y, y_dtype, ldy, heavy_rows,
+                            heavy_chunk_ptr, n_heavy, n_chunks, heavy_thresh, chunk, partial_ws, 0, 1,
+                            stream);
 }
 
 namespace {

@@ -242,11 +242,14 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
               edge_w: Optional[torch.Tensor] = None, dst_scale: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
               slope: float = 0.01, out: Optional[torch.Tensor] = None,
-              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+              out_dtype: Optional[torch.dtype] = None, accumulate: bool = False,
+              finalize: bool = True) -> torch.Tensor:
     """Y = act(dst_scale * (A (src_scale * X) with edge weights) + bias), one fused launch
     (plus two for hub rows).  X and Y are stored as float32 or bfloat16 (sums are float32;
     Y defaults to X's type); scales and bias are float32.  No autograd here; see
-    ops.GcnAggregate."""
+    ops.GcnAggregate.  `accumulate` adds the sums to what `out` holds and `finalize=False`
+    leaves out scaling, bias and activation: a sum over several batches of sources is a chain
+    of such calls (float32 `out`), the last one with `finalize=True`."""
     nv.require_cuda(x, src_scale, edge_w, dst_scale, bias, out)
     if x.dim() != 2 or x.dtype not in _DTYPE_CODES:
         raise nv.SpmiError(f"aggregate expects a 2-D float32/bfloat16 feature matrix, got "
@@ -260,8 +263,12 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
                        ("dst_scale", dst_scale, csr.n_rows), ("bias", bias, feat)):
         if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous()):
             raise nv.SpmiError(f"{name} must be contiguous float32 with {n} elements")
+    if accumulate and out is None:
+        raise nv.SpmiError("aggregate(accumulate=True) needs the `out` tensor of the earlier calls")
     if out is None:
-        out = torch.empty(csr.n_rows, feat, dtype=out_dtype or x.dtype, device=x.device)
+        partial_sums = accumulate or not finalize
+        out = torch.empty(csr.n_rows, feat, dtype=out_dtype or (torch.float32 if partial_sums else x.dtype),
+                          device=x.device)
     elif out.shape != (csr.n_rows, feat) or out.dtype not in _DTYPE_CODES or out.stride(1) != 1:
         raise nv.SpmiError("bad `out` tensor")
     with torch.cuda.device(x.device):
@@ -269,13 +276,13 @@ def aggregate(csr: CSR, x: torch.Tensor, src_scale: Optional[torch.Tensor] = Non
         if _launch_log is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        nv.check(nv.lib().spmi_gcn_spmm_ex(
+        nv.check(nv.lib().spmi_gcn_spmm_part(
             nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.n_cols, csr.nnz,
             nv.ptr(x), _DTYPE_CODES[x.dtype], x.stride(0), feat, nv.ptr(src_scale), nv.ptr(edge_w),
             nv.ptr(dst_scale), nv.ptr(bias), _ACT_CODES[act], float(slope), nv.ptr(out),
             _DTYPE_CODES[out.dtype], out.stride(0), nv.ptr(csr.heavy_rows),
             nv.ptr(csr.heavy_chunk_ptr), csr.n_heavy, csr.n_chunks, csr.heavy_thresh, csr.chunk,
-            nv.ptr(partial), nv.stream()), "spmi_gcn_spmm_ex")
+            nv.ptr(partial), int(accumulate), int(finalize), nv.stream()), "spmi_gcn_spmm_part")
         if _launch_log is not None:
             ev1.record()
             _launch_log.append((ev0, ev1, csr.nnz, csr.n_rows, feat))

@@ -129,11 +129,12 @@ def _gemm_rows_ok(x: torch.Tensor, k: int, n: int) -> bool:
 
 def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Tensor] = None,
               act: Optional[str] = None, slope: float = 0.01,
-              row_scale: Optional[torch.Tensor] = None, planes: Optional[torch.Tensor] = None
-              ) -> torch.Tensor:
+              row_scale: Optional[torch.Tensor] = None, planes: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(x @ weight_nk.T + bias) * row_scale[:, None] for x [rows, K] and weight_nk [N, K] in
     one launch of spmi_gemm_rows; the caller has checked `_gemm_rows_ok(x, K, N)`.  `planes`:
-    `weight_planes(...)` of the same weight, for callers that hold it across calls."""
+    `weight_planes(...)` of the same weight, for callers that hold it across calls.  `out`:
+    float32 [rows, N] with unit column stride to write into (e.g. the head of a larger table)."""
     n, k = weight_nk.shape
     if planes is None:
         planes = split_f16x3(weight_nk)
@@ -142,10 +143,14 @@ def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Ten
                                   or not row_scale.is_contiguous()):
         raise nv.SpmiError("gemm_rows: row_scale must be a contiguous float32 vector with one entry per row")
     with torch.cuda.device(x.device):
-        out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
+        elif (out.shape != (x.shape[0], n) or out.dtype != torch.float32 or out.stride(1) != 1
+              or out.device != x.device):
+            raise nv.SpmiError("gemm_rows: `out` must be float32 [rows, N] on x's device, unit column stride")
         nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), x.stride(0), x.shape[0], k, nv.ptr(planes), n,
                                          nv.ptr(b), nv.ptr(row_scale), _ACT_CODES[act], float(slope),
-                                         nv.ptr(out), n, nv.stream()), "spmi_gemm_rows")
+                                         nv.ptr(out), out.stride(0), nv.stream()), "spmi_gemm_rows")
     return out
 
 

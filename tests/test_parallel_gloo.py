@@ -2,9 +2,10 @@
 
 No GPU here, so the local kernels are replaced by the CPU oracle (as a stand-in for
 libspmi; the kernels themselves are checked in the -m gpu tests).  What is under test:
-edge-balanced block bounds, the padded all-gather layout and id remapping, the
-reduce-scatter of the transposed aggregation, the out-degree all-reduce and the
-gradient all-reduce.  The sharded result must equal the single-process oracle."""
+edge-balanced block bounds, the exchange plan (which rows travel where, the compact source
+table and its column numbering, batches), the all-to-all of the needed rows and its reverse
+in the backward pass, the out-degree all-reduce and the gradient all-reduce.  The sharded
+result must equal the single-process oracle, for 2 and 3 ranks and 1 to 3 batches."""
 import os
 import socket
 from types import SimpleNamespace
@@ -28,14 +29,26 @@ def _cpu_kernels():
         def degrees(self):
             return (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
 
-    def build_csr(key, other, n_key, n_other, *_):
+    def build_csr(key, other, n_key, n_other, *_, **__):
         return CpuCSR(*orc.coo_to_csr(key.numpy(), other.numpy(), n_key, n_other), n_key, n_other)
 
-    def aggregate(csr, x, src_scale=None, edge_w=None, dst_scale=None, bias=None, act=None, slope=0.01):
-        n = lambda t: None if t is None else t.detach().numpy()
+    def aggregate(csr, x, src_scale=None, edge_w=None, dst_scale=None, bias=None, act=None, slope=0.01,
+                  out=None, out_dtype=None, accumulate=False, finalize=True):
+        n = lambda t: None if t is None else t.detach().float().numpy()
         assert x.shape[0] == csr.n_cols
-        return torch.from_numpy(orc.aggregate(csr.indptr.numpy(), csr.indices.numpy(), n(x), n(src_scale), n(edge_w),
-                                              n(dst_scale), n(bias), act, slope))
+        if not accumulate and finalize:
+            return torch.from_numpy(orc.aggregate(csr.indptr.numpy(), csr.indices.numpy(), n(x), n(src_scale),
+                                                  n(edge_w), n(dst_scale), n(bias), act, slope))
+        raw = torch.from_numpy(orc.aggregate(csr.indptr.numpy(), csr.indices.numpy(), n(x), n(src_scale), n(edge_w)))
+        if accumulate:
+            raw = raw + out
+        if finalize:
+            if dst_scale is not None:
+                raw = raw * dst_scale[:, None]
+            if bias is not None:
+                raw = raw + bias
+            raw = torch.from_numpy(orc._activation(raw.numpy(), act, slope))
+        return raw
 
     def degree(ids, n):
         return torch.from_numpy(orc.degree(ids.numpy(), n))
@@ -62,7 +75,7 @@ def _problem(fi, fo):
     return n, src, dst, x, w, b
 
 
-def _worker(rank, world, port, fi, fo, act, results):
+def _worker(rank, world, port, fi, fo, act, stages, results):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -74,7 +87,8 @@ def _worker(rank, world, port, fi, fo, act, results):
         bounds = par.edge_balanced_bounds(torch.from_numpy(orc.degree(dst, n)), world)
         part = par.RowPartition(n, bounds, rank, world)
         lo, hi = part.block()
-        shard = par.ShardedSnapshot.from_global(torch.from_numpy(src), torch.from_numpy(dst), part)
+        shard = par.ShardedSnapshot.from_global(torch.from_numpy(src), torch.from_numpy(dst), part,
+                                                stages=stages)
         conv = GraphConv(fi, fo, activation={"relu": F.relu, None: None}[act], allow_zero_in_degree=True)
         with torch.no_grad():
             conv.weight.copy_(torch.from_numpy(w))
@@ -83,9 +97,20 @@ def _worker(rank, world, port, fi, fo, act, results):
         y = par.sharded_graphconv(conv, shard, xl)
         (y ** 2).sum().backward()
         par.allreduce_gradients(conv)
-        results[rank] = dict(bounds=bounds, y=y.detach().numpy(), gx=xl.grad.numpy(),
-                             gw=conv.weight.grad.numpy(), gb=conv.bias.grad.numpy(),
-                             nnz=shard.csr().nnz)
+        out = dict(bounds=bounds, y=y.detach().numpy(), gx=xl.grad.numpy(),
+                   gw=conv.weight.grad.numpy(), gb=conv.bias.grad.numpy(), nnz=shard.csr().nnz,
+                   n_table=shard.plan.n_table, n_local=shard.n_local,
+                   table_ids=shard.plan.table_ids.numpy(), sent=int(shard.plan.send_index.numel()),
+                   needed=np.unique(src[(dst >= lo) & (dst < hi)]))
+        with torch.no_grad():                      # the two halves, batch by batch
+            y_ng = par.sharded_graphconv(conv, shard, xl.detach())
+            y_rep = par.graphconv_replicated(conv, shard, torch.from_numpy(x))
+        conv.zero_grad()
+        y_rep_t = par.graphconv_replicated(conv, shard, torch.from_numpy(x))
+        (y_rep_t ** 2).sum().backward()
+        par.allreduce_gradients(conv)
+        out.update(y_ng=y_ng.numpy(), y_rep=y_rep.numpy(), gw_rep=conv.weight.grad.numpy())
+        results[rank] = out
     finally:
         dist.destroy_process_group()
 
@@ -96,12 +121,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("fi,fo,act", [(12, 6, "relu"), (8, 8, None)])
-def test_two_rank_graphconv_equals_single_process(fi, fo, act):
-    world = 2
+@pytest.mark.parametrize("world,fi,fo,act,stages", [(2, 12, 6, "relu", 1), (2, 8, 8, None, 2),
+                                                    (3, 8, 12, "relu", 3), (3, 12, 6, None, 1)])
+def test_sharded_graphconv_equals_single_process(world, fi, fo, act, stages):
     with mp.Manager() as mgr:
         results = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), fi, fo, act, results), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), fi, fo, act, stages, results), nprocs=world, join=True)
         results = dict(results)
     n, src, dst, x, w, b = _problem(fi, fo)
     xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
@@ -112,61 +137,48 @@ def test_two_rank_graphconv_equals_single_process(fi, fo, act):
         return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
 
     bounds = results[0]["bounds"]
-    assert bounds == results[1]["bounds"] and bounds[0] == 0 and bounds[-1] == n
+    assert all(results[r]["bounds"] == bounds for r in range(world)) and bounds[0] == 0 and bounds[-1] == n
     e = len(src)
-    assert results[0]["nnz"] + results[1]["nnz"] == e
-    assert abs(results[0]["nnz"] - e / 2) < 0.15 * e  # cut at equal nonzeros, hub rows permitting
+    assert sum(results[r]["nnz"] for r in range(world)) == e
+    assert abs(results[0]["nnz"] - e / world) < 0.15 * e  # cut at equal nonzeros, hub rows permitting
+    received = 0
     for r in range(world):
         lo, hi = bounds[r], bounds[r + 1]
-        assert rel(results[r]["y"], y_ref.detach().numpy()[lo:hi]) < 1e-5
-        assert rel(results[r]["gx"], xt.grad.numpy()[lo:hi]) < 1e-5
-        assert rel(results[r]["gw"], wt.grad.numpy()) < 1e-5
-        assert rel(results[r]["gb"], bt.grad.numpy()) < 1e-5
+        res = results[r]
+        # the source table: own block in place, then exactly the remote rows this rank's edges name
+        remote = res["needed"][(res["needed"] < lo) | (res["needed"] >= hi)]
+        assert res["n_table"] == res["n_local"] + len(remote)
+        np.testing.assert_array_equal(res["table_ids"][: hi - lo], np.arange(lo, hi))
+        np.testing.assert_array_equal(np.sort(res["table_ids"][hi - lo:]), remote)
+        received += len(remote)
+        assert rel(res["y"], y_ref.detach().numpy()[lo:hi]) < 1e-5
+        assert rel(res["y_ng"], y_ref.detach().numpy()[lo:hi]) < 1e-5
+        assert rel(res["y_rep"], y_ref.detach().numpy()[lo:hi]) < 1e-5
+        assert rel(res["gx"], xt.grad.numpy()[lo:hi]) < 1e-5
+        assert rel(res["gw"], wt.grad.numpy()) < 1e-5
+        assert rel(res["gb"], bt.grad.numpy()) < 1e-5
+        assert rel(res["gw_rep"], wt.grad.numpy()) < 1e-5
+    assert sum(results[r]["sent"] for r in range(world)) == received   # every row sent is a row needed
+    assert received < (world - 1) * n                                    # less than an all-gather moves
 
 
-def test_bounds_and_padded_layout():
+def test_bounds_and_slices():
     deg = torch.tensor([5, 0, 0, 1, 1, 1, 1, 1, 0, 0])
     b = par.edge_balanced_bounds(deg, 2)
-    assert b == [0, 1, 10] or b == [0, 3, 10] or b[1] in (1, 2, 3, 4)
+    assert b[0] == 0 and b[-1] == 10 and b[1] in (1, 2, 3, 4)
     assert sum(deg[: b[1]]) >= 5
     part = par.RowPartition(10, [0, 3, 10], 1, 2)
-    assert part.max_block == 7 and part.n_gather == 14 and part.block() == (3, 10)
-    ids = torch.tensor([0, 2, 3, 9])
-    assert part.padded_rows(ids).tolist() == [0, 2, 7, 13]
-    one = par.edge_balanced_bounds(deg, 1)
-    assert one == [0, 10]
+    assert part.block() == (3, 10) and part.block(0) == (0, 3)
+    assert part.owner(torch.tensor([0, 2, 3, 9])).tolist() == [0, 0, 1, 1]
+    assert par.edge_balanced_bounds(deg, 1) == [0, 10]
+    assert par._slice_bounds(10, 3) == [0, 3, 6, 10] and par._slice_bounds(0, 2) == [0, 0, 0]
 
 
-def _gather_worker(rank, world, port, results):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        n, f = 11, 3
-        part = par.RowPartition(n, [0, 4, 11], rank, world)
-        x = torch.arange(n * f, dtype=torch.float32).reshape(n, f)
-        lo, hi = part.block()
-        pending = par.gather_rows_async(x[lo:hi] * 2.0, part)
-        repl = par.replicate_rows(x, part)  # independent work while the rows travel
-        results[rank] = dict(gathered=pending.wait().numpy(), repl=repl.numpy())
-    finally:
-        dist.destroy_process_group()
-
-
-def test_async_gather_and_replicated_layout_agree():
-    """The gathered matrix of per-rank blocks and the replicated layout of the same global
-    matrix address rows identically (RowPartition.padded_rows); padding rows are zero."""
-    world = 2
-    with mp.Manager() as mgr:
-        results = mgr.dict()
-        mp.spawn(_gather_worker, args=(world, _free_port(), results), nprocs=world, join=True)
-        results = dict(results)
-    n, f = 11, 3
-    x = np.arange(n * f, dtype=np.float32).reshape(n, f)
-    part = par.RowPartition(n, [0, 4, 11], 0, world)
-    rows = part.padded_rows(torch.arange(n)).numpy()
-    for r in range(world):
-        assert results[r]["gathered"].shape == (part.n_gather, f)
-        np.testing.assert_array_equal(results[r]["gathered"][rows], 2.0 * x)
-        np.testing.assert_array_equal(results[r]["repl"][rows], x)
-        pad = np.setdiff1d(np.arange(part.n_gather), rows)
-        assert not results[r]["repl"][pad].any() and not results[r]["gathered"][pad].any()
+def test_single_rank_plan_needs_no_process_group():
+    """world = 1: the table is the block itself and nothing is exchanged."""
+    part = par.RowPartition(6, [0, 6], 0, 1)
+    plan = par.ExchangePlan(torch.tensor([5, 0, 0, 3]), part, stages=2)
+    assert plan.n_table == 6 and plan.n_remote == 0
+    assert plan.columns(torch.tensor([5, 0, 3])).tolist() == [5, 0, 3]
+    pending = par.exchange_rows_async(torch.arange(12.0).reshape(6, 2), plan)
+    assert torch.equal(pending.wait(), torch.arange(12.0).reshape(6, 2))
