@@ -12,7 +12,9 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libspmi.so")
+# SPMI_LIB_PATH: another build of the same library, for A/B timing of kernel variants
+_LIB_PATH = os.environ.get("SPMI_LIB_PATH") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "libspmi.so")
 _lib: Optional[ctypes.CDLL] = None
 
 c_i64, c_i32, c_int, c_f32, c_vp, c_sz = (

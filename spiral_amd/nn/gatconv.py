@@ -26,8 +26,9 @@ class GATConv(nn.Module):
                  attn_drop: float = 0.0, negative_slope: float = 0.2, residual: bool = False,
                  activation=None, allow_zero_in_degree: bool = False, bias: bool = True):
         super().__init__()
-        if attn_drop:
-            raise NotImplementedError("attention dropout is not implemented")
+        if not 0.0 <= attn_drop < 1.0:
+            raise ValueError(f"attn_drop must be in [0, 1), got {attn_drop}")
+        self._attn_drop = float(attn_drop)
         self._num_heads = num_heads
         self._in_src_feats = self._in_dst_feats = in_feats
         self._out_feats = out_feats
@@ -80,7 +81,8 @@ class GATConv(nn.Module):
         code, slope, unfused = _classify_activation(self.activation)
         fuse = self.res_fc is None  # bias and activation ride in the aggregation epilogue
         rst, attn = gat_aggregate(graph, ft, el, er, heads, self._negative_slope,
-                                  self.bias if fuse else None, code if fuse else None, slope)
+                                  self.bias if fuse else None, code if fuse else None, slope,
+                                  attn_drop=self._attn_drop if self.training else 0.0)
         if not fuse:
             rst = rst + self.res_fc(h)
             if self.bias is not None:

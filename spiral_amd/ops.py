@@ -358,28 +358,34 @@ class GatAggregate(torch.autograd.Function):
     dense projections).  ft [N, H*D], el / er [N, H]."""
 
     @staticmethod
-    def forward(ctx, ft, el, er, bias, g, heads, slope, act, act_slope):
+    def forward(ctx, ft, el, er, bias, g, heads, slope, act, act_slope, attn_drop):
         csr = g.csr()
         n, width = ft.shape
         d = width // heads
         need_grad = _needs_grad(ctx, 3)
         ft_c, el_c, er_c = ft.detach().contiguous(), el.detach().contiguous(), er.detach().contiguous()
         attn, raw = edge_softmax_scores(csr, el_c, er_c, slope, need_grad)
+        # attention dropout (dgl GATConv: `attn_drop(edge_softmax(graph, e))`): the weights that
+        # survive are scaled by 1 / (1 - p); `used` is what the weighted sum multiplies by
+        keep = None
+        if attn_drop > 0.0:
+            keep = (torch.rand_like(attn) >= attn_drop).to(attn.dtype) / (1.0 - attn_drop)
+        used = attn if keep is None else attn * keep
         out = torch.empty(csr.n_rows, width, dtype=torch.float32, device=ft.device)
         b = None if bias is None else bias.detach()
         for h in range(heads):
             cols = slice(h * d, (h + 1) * d)
-            aggregate(csr, ft_c[:, cols], None, attn[h], None, None if b is None else b[cols], act,
+            aggregate(csr, ft_c[:, cols], None, used[h], None, None if b is None else b[cols], act,
                       act_slope, out=out[:, cols])
         ctx.g, ctx.heads, ctx.slope, ctx.act, ctx.act_slope = g, heads, slope, act, act_slope
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(ft_c, attn, raw, out if act not in (None, "none") else None)
-        ctx.mark_non_differentiable(attn)
-        return out, attn
+        ctx.save_for_backward(ft_c, attn, raw, out if act not in (None, "none") else None, keep)
+        ctx.mark_non_differentiable(used)
+        return out, used
 
     @staticmethod
     def backward(ctx, g_out, _g_attn):
-        ft, attn, raw, out = ctx.saved_tensors
+        ft, attn, raw, out, keep = ctx.saved_tensors
         g, heads = ctx.g, ctx.heads
         need_b = ctx.needs_input_grad[3] and ctx.has_bias
         g_p, g_b = g_out.contiguous(), None
@@ -396,7 +402,7 @@ class GatAggregate(torch.autograd.Function):
             raise nv.SpmiError(f"attention backward needs a head width that is a power of two below "
                                f"64 or a multiple of 64 (got {d}) and heads*width <= 512")
         # gradient of the projected source rows through the weighted sum
-        attn_t = attn.index_select(1, t2f)
+        attn_t = (attn if keep is None else attn * keep).index_select(1, t2f)
         g_ft = torch.empty_like(ft)
         for h in range(heads):
             cols = slice(h * d, (h + 1) * d)
@@ -406,6 +412,8 @@ class GatAggregate(torch.autograd.Function):
             nv.check(lib.spmi_sddmm_dot(nv.ptr(csr.indptr), nv.ptr(csr.indices), csr.n_rows, csr.nnz,
                                         nv.ptr(g_p), g_p.stride(0), nv.ptr(ft), ft.stride(0), heads, d,
                                         nv.ptr(d_attn), nv.stream()), "spmi_sddmm_dot")
+            if keep is not None:
+                d_attn = d_attn * keep   # through the dropout: dropped weights pass no gradient
             d_raw = torch.empty_like(attn)
             g_er = torch.empty(csr.n_rows, heads, dtype=torch.float32, device=ft.device)
             nv.check(lib.spmi_gat_edge_softmax_bwd(
@@ -417,19 +425,20 @@ class GatAggregate(torch.autograd.Function):
             nv.check(lib.spmi_segment_sum(nv.ptr(csr_t.indptr), csr_t.n_rows, csr_t.nnz,
                                           nv.ptr(d_raw_t), heads, nv.ptr(g_el), *_heavy(csr_t),
                                           nv.stream()), "spmi_segment_sum")
-        return g_ft, g_el, g_er, g_b, None, None, None, None, None
+        return g_ft, g_el, g_er, g_b, None, None, None, None, None, None
 
 
 def gat_aggregate(g, ft: torch.Tensor, el: torch.Tensor, er: torch.Tensor, heads: int,
                   negative_slope: float = 0.2, bias: Optional[torch.Tensor] = None,
-                  act: Optional[str] = None, act_slope: float = 0.01):
+                  act: Optional[str] = None, act_slope: float = 0.01, attn_drop: float = 0.0):
     """Differentiable attention aggregation; returns (out [N, H*D], attn [H, E] in the order
-    of g.csr())."""
+    of g.csr()).  `attn_drop` > 0 drops attention weights with that probability (training
+    only: the caller passes 0 in eval mode); the returned weights are the ones used."""
     nv.require_cuda(ft, el, er, bias)
     if ft.dtype != torch.float32 or ft.dim() != 2 or ft.shape[1] % heads:
         raise nv.SpmiError(f"gat_aggregate expects float32 [N, heads*D] features, got {tuple(ft.shape)}")
     return _apply_tracked(GatAggregate, (ft, el, er, bias), ft, el, er, bias, g, heads, float(negative_slope), act,
-                          float(act_slope))
+                          float(act_slope), float(attn_drop))
 
 
 # --------------------------------------------------------------------------- recurrent cells

@@ -105,8 +105,8 @@ def test_zero_in_degree_and_unsupported_widths(dev):
         conv.bias.fill_(0.5)
         y = conv(g, x)
     assert torch.equal(y[0], torch.full((1, 8), 0.5, device=dev))  # no messages: bias only
-    with pytest.raises(NotImplementedError):
-        GATConv(6, 8, 1, attn_drop=0.1)
+    with pytest.raises(ValueError):
+        GATConv(6, 8, 1, attn_drop=1.0)
     # the backward needs a head width the dot-product kernel can split into lane groups
     conv = GATConv(6, 10, 1, allow_zero_in_degree=True).to(dev)
     with torch.no_grad():
@@ -184,3 +184,51 @@ def test_gat_encoder_adds_self_loops(dev):
                                    cpu(conv.bias), heads, 0.2, "leaky_relu")
         ref = ref.reshape(n, heads * hid)
     assert rel(h.detach().cpu(), ref.detach()) < 1e-5
+
+
+def test_attention_dropout(dev):
+    """dgl GATConv applies `attn_drop` to the softmax weights before the weighted sum
+    (reference: GAT passes GATConv keyword arguments through, staticGraphEncoder.py:170-174).
+    In eval mode nothing is dropped; in train mode every returned weight is either 0 or the
+    undropped weight / (1 - p), the output is the weighted sum with exactly those weights, and
+    the gradients equal those of a torch restatement that applies the same realised mask."""
+    n, e, fi, d, heads, p = 1200, 20_000, 16, 32, 2, 0.4
+    src, dst, g = _graph(dev, n, e, seed=77)
+    torch.manual_seed(1)
+    conv = GATConv(fi, d, heads, attn_drop=p, allow_zero_in_degree=True).to(dev)
+    x = torch.randn(n, fi)
+    conv.eval()
+    with torch.no_grad():
+        y_eval, a_eval = conv(g, x.to(dev), get_attention=True)
+    y_ref, a_ref, _, _, _ = _reference(conv, src, dst, n, x, None)
+    assert rel(y_eval.cpu(), y_ref.detach()) < 1e-5 and rel(a_eval.cpu(), a_ref.detach()) < 1e-5
+
+    conv.train()
+    xg = x.to(dev).requires_grad_()
+    y, a = conv(g, xg, get_attention=True)
+    a_cpu = a.detach().cpu()
+    kept = a_cpu != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac                      # the drop rate asked for
+    assert rel(a_cpu[kept], (a_ref.detach() / (1 - p))[kept]) < 1e-5
+    wgt = torch.randn(n, heads, d)
+    (y * wgt.to(dev)).sum().backward()
+
+    # the same layer in torch index ops with the realised mask
+    cpu = lambda t: t.detach().cpu().clone().requires_grad_()
+    fc, al, ar, b, xr = cpu(conv.fc.weight), cpu(conv.attn_l), cpu(conv.attn_r), cpu(conv.bias), x.clone().requires_grad_()
+    src_t, dst_t = torch.from_numpy(src), torch.from_numpy(dst)
+    ft = (xr @ fc.t()).view(-1, heads, d)
+    el, er = (ft * al).sum(-1), (ft * ar).sum(-1)
+    ee = F.leaky_relu(el[src_t] + er[dst_t], conv._negative_slope)
+    m = torch.full((n, heads), -torch.inf).scatter_reduce(0, dst_t[:, None].expand(-1, heads), ee.detach(), "amax")
+    pe = torch.exp(ee - m[dst_t])
+    den = torch.zeros(n, heads).index_add_(0, dst_t, pe)
+    att = pe / den[dst_t] * (kept[:, :, 0].float() / (1 - p))
+    want = torch.zeros(n, heads, d).index_add_(0, dst_t, att[:, :, None] * ft[src_t]) + b.view(1, heads, d)
+    (want * wgt).sum().backward()
+    assert rel(y.detach().cpu(), want.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel(conv.fc.weight.grad.cpu(), fc.grad) < 1e-5
+    assert rel(conv.attn_l.grad.cpu(), al.grad) < 1e-5 and rel(conv.attn_r.grad.cpu(), ar.grad) < 1e-5
+    assert rel(conv.bias.grad.cpu(), b.grad) < 1e-5

@@ -175,3 +175,33 @@ def test_node_memory_spare_table_and_swap():
     assert mem._spare is None and mem.memory.shape == (2, 7, 4)
     moved = mem.to("meta")
     assert moved._spare is None and moved.memory.device.type == "meta"
+
+
+def test_mrr_definition():
+    """Reciprocal rank of each positive among its own negatives (the metric the reference takes
+    from ogb's Evaluator, examples/tf/link_prediction_sliding_window.py:142-146): hand-computed
+    cases, ties counted half, and the script's layout of one evaluation pass."""
+    import torch
+
+    from spiral_amd.automl.evaluate import link_prediction_mrr, mrr
+
+    pos = torch.tensor([0.9, 0.2, 0.5])
+    neg = torch.tensor([[0.1, 0.3, 0.5], [0.7, 0.3, 0.1], [0.5, 0.5, 0.9]])
+    out = mrr(pos, neg)
+    # ranks: 1 (nothing above); 3 (two above); 1 above + 2 ties -> 0.5 * (1 + 3) + 1 = 3
+    assert torch.allclose(out["mrr_list"], torch.tensor([1.0, 1 / 3, 1 / 3]))
+    assert out["hits@1_list"].tolist() == [1.0, 0.0, 0.0] and out["hits@3_list"].tolist() == [1.0, 1.0, 1.0]
+    # without ties the rank is the position in the descending sort (ogb's argsort form)
+    gen = torch.Generator().manual_seed(0)
+    p, n = torch.rand(50, generator=gen), torch.rand(50, 20, generator=gen)
+    order = torch.argsort(torch.cat([p[:, None], n], 1), dim=1, descending=True)
+    want = 1.0 / ((order == 0).nonzero()[:, 1] + 1).float()
+    assert torch.allclose(mrr(p, n)["mrr_list"], want)
+    # two evaluated nodes, two positives each, three negatives per node
+    scores = torch.tensor([0.9, 0.4, 0.8, 0.1, 0.5, 0.3, 0.2, 0.6, 0.7, 0.0])
+    got = link_prediction_mrr(scores, n_pos=4, negatives_per_node=3)
+    want = (1 / 1 + 1 / 2 + 1 / 1 + 1 / 3) / 4   # node 0 negatives .5 .3 .2, node 1 negatives .6 .7 0
+    assert abs(got - want) < 1e-6
+    import pytest
+    with pytest.raises(ValueError):
+        mrr(torch.rand(3), torch.rand(4, 2))
