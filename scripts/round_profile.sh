@@ -10,7 +10,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 240 python3 bench.py > $out/bench_line.json 2> $out/bench.err
 echo "bench done"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline > $out/bench_profiled_line.json 2> $out/prof.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-train-probe > $out/bench_profiled_line.json 2> $out/prof.err
 echo "profile done"
 python3 scripts/step_timeline.py $(ls $out/prof/*kernel_trace.csv | head -1) > $out/step_timeline.txt
 for w in config3 config4 config5 small; do
@@ -19,5 +19,5 @@ for w in config3 config4 config5 small; do
 done
 timeout -k 10 240 python3 bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_train.json 2>> $out/bench.err
 echo "train done"
-SPMI_BENCH_REHEARSE=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_rehearse2.json 2> $out/rehearse.err
+scripts/rehearse_bench.sh small > $out/rehearse.txt
 echo "rehearsal done"

@@ -1,7 +1,7 @@
 """profiles/r01_spmm_traffic.json from two `rocprofv3 --pmc` passes over scripts/pmc_spmm.py
 (FETCH_SIZE in one run, WRITE_SIZE in another):
 
-    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv>
+    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag]
 
 Launch groups alternate calibration / benchmark (three repetitions); a group is the stream
 kernel plus, when the graph has hub rows, the two heavy-row kernels.  The read counter is
@@ -51,7 +51,7 @@ def main():
                 "counter is scaled by the factor that makes the calibration launch match its known traffic",
     }
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                       "r01_spmm_traffic.json")
+                       f"{sys.argv[3] if len(sys.argv) > 3 else 'rXX'}_spmm_traffic.json")
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(doc, indent=1))
