@@ -548,13 +548,17 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- kernel-level numbers of the fused aggregation (this rank) ------------------------
+    # every launch is priced with its own edge count, row count and width (layers of one model
+    # may aggregate rows of different widths): achieved = total algorithmic bytes / total time
     spmm_ms = [a.elapsed_time(b) for a, b, *_ in launch_log]
+    store_bytes = 2 if kind == "evolve_bf16" else 4
+    launch_bytes = [algorithmic_bytes(l[2], l[3], l[4], store_bytes) for l in launch_log]
     _, _, nnz, n_rows, feat = launch_log[0]
+    widths = sorted({l[4] for l in launch_log})
     mean_nnz = sum(l[2] for l in launch_log) / len(launch_log)
     spmm_avg_ms = sum(spmm_ms) / len(spmm_ms)
-    store_bytes = 2 if kind == "evolve_bf16" else 4
-    alg_bytes = algorithmic_bytes(mean_nnz, n_rows, feat, store_bytes)
-    achieved = alg_bytes / (spmm_avg_ms * 1e-3) / 1e9
+    alg_bytes = sum(launch_bytes) / len(launch_bytes)
+    achieved = sum(launch_bytes) / (sum(spmm_ms) * 1e-3) / 1e9
     stages = {}
     if pipelined:
         # front(t): [0,1) CSR, [1,2) layer 1, [2,3) projection + gather start;
@@ -661,7 +665,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
-                "kernel": aggregation_kernel_name(feat, kind == "evolve_bf16"),
+                "kernel": "; ".join(aggregation_kernel_name(fw, kind == "evolve_bf16") for fw in widths),
+                "feature_widths": widths,
                 "avg_launch_ms": spmm_avg_ms, "launches": len(spmm_ms),
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
