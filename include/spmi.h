@@ -419,6 +419,17 @@ size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int spmi_gemm_tn(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/, int64_t ldb,
                  int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
+/* The same product with the column sums of its operands on the side: col_sum_a[m] = sum_k A[k,m],
+ * col_sum_b[n] = sum_k B[k,n] (each nullable).  In the training loop the bias gradient of a dense
+ * layer is the column sum of the very matrix its weight gradient multiplies (db = sum_rows dY
+ * next to dW = X^T dY: the autograd of `+ bias` in dgl GraphConv.forward, nn.GRU/LSTM/RNN and
+ * nn.Linear, same reference lines as spmi_gemm_tn), so the sum costs one add per element
+ * already in a register instead of another pass over a [nodes, width] matrix.  Fixed
+ * summation order (bit-reproducible).  Workspace as for spmi_gemm_tn. */
+int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/, int64_t ldb,
+                      int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc,
+                      int accumulate, float* col_sum_a /*nullable [M]*/,
+                      float* col_sum_b /*nullable [N]*/, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Output head in inference, one kernel: the MLP of

@@ -32,7 +32,8 @@ constexpr int kUnroll = 8;  // k-pairs per loop trip (16 rows of A and B)
 template <int NT>
 __global__ __launch_bounds__(kThreads) void gemm_tn_partial_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
-    int M, int N, int64_t k_chunk, float* __restrict__ partial, int m_strips, int n_tiles) {
+    int M, int N, int64_t k_chunk, float* __restrict__ partial, int m_strips, int n_tiles,
+    float* __restrict__ sum_a_partial, float* __restrict__ sum_b_partial) {
   const int lane = threadIdx.x & 63;
   const int st = static_cast<int>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
   if (st >= m_strips * n_tiles) return;
@@ -62,6 +63,14 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_partial_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 
+  // Column sums of the operands ride along: the waves of the first column tile add up what
+  // they load of A, the waves of the first row strip what they load of B (one add per load).
+  const bool want_sa = sum_a_partial != nullptr && n0 == 0;
+  const bool want_sb = sum_b_partial != nullptr && m0 == 0;
+  float sa = 0.0f, sb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sb[t] = 0.0f;
+
   int64_t k = k_begin;
   for (; k + 2 * kUnroll <= k_end; k += 2 * kUnroll) {
     float a[kUnroll], b[kUnroll][NT];
@@ -76,19 +85,36 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_partial_kernel(
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const float av = a_ok ? a[u] : 0.0f;
+      sa += av;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_ok[t] ? b[u][t] : 0.0f, acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        const float bv = b_ok[t] ? b[u][t] : 0.0f;
+        sb[t] += bv;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
     }
   }
   for (; k < k_end; k += 2) {  // tail of the chunk: rows past k_end contribute zero
     const bool r_ok = k + lh < k_end;
     const int64_t kk = r_ok ? k : k - 1;  // k >= k_begin + 1 when lh == 1 overruns; stays inside
     const float av = (a_ok && r_ok) ? (A + kk * lda)[a_off] : 0.0f;
+    sa += av;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float bv = (b_ok[t] && r_ok) ? (B + kk * ldb)[b_off[t]] : 0.0f;
+      sb[t] += bv;
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+  if (want_sa) {  // even and odd rows of the chunk sit in the two lane halves
+    sa += __shfl_xor(sa, 32);
+    if (lh == 0 && a_ok) sum_a_partial[static_cast<size_t>(blockIdx.y) * M + m0 + lr] = sa;
+  }
+  if (want_sb) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float v = sb[t] + __shfl_xor(sb[t], 32);
+      if (lh == 0 && b_ok[t]) sum_b_partial[static_cast<size_t>(blockIdx.y) * N + n0 + 32 * t + lr] = v;
     }
   }
 
@@ -175,12 +201,19 @@ extern "C" {
 size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || M > 4096 || N > 4096) return 0;
   const Shape s = plan(M, N, K);
-  return sizeof(float) * static_cast<size_t>(s.n_chunks) * M * N;
+  return sizeof(float) * static_cast<size_t>(s.n_chunks) * (M * N + M + N);
 }
 
 int spmi_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t M,
                  int64_t N, float* C, int64_t ldc, int accumulate, void* ws, size_t ws_bytes,
                  void* stream) {
+  return spmi_gemm_tn_sums(A, lda, B, ldb, K, M, N, C, ldc, accumulate, nullptr, nullptr, ws, ws_bytes,
+                           stream);
+}
+
+int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t M,
+                      int64_t N, float* C, int64_t ldc, int accumulate, float* col_sum_a,
+                      float* col_sum_b, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_gemm_tn(M, N, K)) return rc;
   SPMI_REQUIRE(A && B && C && ws, SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: null pointer argument");
   SPMI_REQUIRE(lda >= M && ldb >= N && ldc >= N, SPMI_ERR_INVALID_ARG,
@@ -192,10 +225,12 @@ int spmi_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64
   const Shape s = plan(M, N, K);
   hipStream_t st = spmi::as_stream(stream);
   float* partial = static_cast<float*>(ws);
+  float* pa = col_sum_a ? partial + static_cast<size_t>(s.n_chunks) * M * N : nullptr;
+  float* pb = col_sum_b ? partial + static_cast<size_t>(s.n_chunks) * (M * N + M) : nullptr;
   const dim3 grid((s.m_strips * s.n_tiles + kWaves - 1) / kWaves, s.n_chunks);
 #define SPMI_GEMM_TN(NT)                                                                        \
   gemm_tn_partial_kernel<NT><<<grid, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N,     \
-                                                        s.k_chunk, partial, s.m_strips, s.n_tiles)
+                                                        s.k_chunk, partial, s.m_strips, s.n_tiles, pa, pb)
   if (s.nt == 4) SPMI_GEMM_TN(4);
   else if (s.nt == 2) SPMI_GEMM_TN(2);
   else SPMI_GEMM_TN(1);
@@ -212,6 +247,24 @@ int spmi_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64
                                                           accumulate);
   }
   SPMI_CHECK_LAUNCH("gemm_tn_reduce");
+  // the operand column sums: the same fixed-order chunk reduction over vectors of M / N entries
+  const float* vec_src[2] = {pa, pb};
+  float* vec_dst[2] = {col_sum_a, col_sum_b};
+  const int64_t vec_len[2] = {M, N};
+  for (int v = 0; v < 2; ++v) {
+    if (!vec_dst[v]) continue;
+    const int64_t len = vec_len[v];
+    if (s.n_chunks >= 64) {
+      const unsigned blocks = static_cast<unsigned>((len + 4 * kWaves - 1) / (4 * kWaves));
+      gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(vec_src[v], s.n_chunks, len, (int)len,
+                                                             vec_dst[v], len, 0);
+    } else {
+      const unsigned blocks = static_cast<unsigned>((len + kThreads - 1) / kThreads);
+      gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(vec_src[v], s.n_chunks, len, (int)len,
+                                                            vec_dst[v], len, 0);
+    }
+    SPMI_CHECK_LAUNCH("gemm_tn_reduce(sums)");
+  }
   return SPMI_OK;
 }
 

@@ -91,25 +91,48 @@ def gcn_aggregate(g, x: torch.Tensor, norm: str = "both", bias: Optional[torch.T
 GEMM_TN_MIN_ROWS = 16384  # below this many rows the library GEMM is as good
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, sum_a: bool = False, sum_b: bool = False):
     """a^T b for two tall matrices sharing their row count (a weight gradient X^T dY): the
     split-K matrix-core kernel of libspmi for tall shapes with a small output (where it is
-    2-3x faster than the library GEMM), the library GEMM otherwise."""
+    2-3x faster than the library GEMM), the library GEMM otherwise.  With `sum_a` / `sum_b`
+    the column sums of the operands come back as well, as `(product, a.sum(0) or None,
+    b.sum(0) or None)`: a bias gradient is the column sum of a matrix the kernel reads anyway."""
     k, m = a.shape
     n = b.shape[1]
+    sums = sum_a or sum_b
     if (k < GEMM_TN_MIN_ROWS or m * n > 512 * 512 or a.dtype != torch.float32
             or b.dtype != torch.float32 or not a.is_cuda):
-        return a.t() @ b
+        out = a.t() @ b
+        return (out, a.sum(0) if sum_a else None, b.sum(0) if sum_b else None) if sums else out
     a = a if a.stride(1) == 1 else a.contiguous()
     b = b if b.stride(1) == 1 else b.contiguous()
     lib = nv.lib()
     with torch.cuda.device(a.device):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        sa = torch.empty(m, dtype=torch.float32, device=a.device) if sum_a else None
+        sb = torch.empty(n, dtype=torch.float32, device=a.device) if sum_b else None
         ws_bytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-        nv.check(lib.spmi_gemm_tn(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n, nv.ptr(out),
-                                  n, 0, nv.ptr(ws), ws_bytes, nv.stream()), "spmi_gemm_tn")
-    return out
+        nv.check(lib.spmi_gemm_tn_sums(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n,
+                                       nv.ptr(out), n, 0, nv.ptr(sa), nv.ptr(sb), nv.ptr(ws), ws_bytes,
+                                       nv.stream()), "spmi_gemm_tn_sums")
+    return (out, sa, sb) if sums else out
+
+
+def _weight_and_bias_grad(dy: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, dy_first: bool):
+    """(dW, db) of a dense layer from dY and its input: dW = dY^T x (`dy_first`) or x^T dY,
+    db = column sums of dY, taken from the same pass over dY when both are wanted."""
+    g_w = g_b = None
+    if need_w and need_b:
+        if dy_first:
+            g_w, g_b, _ = gemm_tn(dy, x, sum_a=True)
+        else:
+            g_w, _, g_b = gemm_tn(x, dy, sum_b=True)
+    elif need_w:
+        g_w = gemm_tn(dy, x) if dy_first else gemm_tn(x, dy)
+    elif need_b:
+        g_b = dy.sum(0)
+    return g_w, g_b
 
 
 # Projections of a tall matrix by a small weight: "f16x3" = libspmi's memory-speed kernel on
@@ -200,8 +223,8 @@ class _RowsTimesWeight(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         g_x = _mm_nk(g, w) if ctx.needs_input_grad[0] else None
-        g_w = gemm_tn(x, g) if ctx.needs_input_grad[1] else None
-        g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        g_w, g_b = _weight_and_bias_grad(g, x, ctx.needs_input_grad[1],
+                                         ctx.has_bias and ctx.needs_input_grad[2], dy_first=False)
         return g_x, g_w, g_b
 
 
@@ -230,8 +253,8 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         g_x = _mm(g, weight) if ctx.needs_input_grad[0] else None
-        g_w = gemm_tn(g, x) if ctx.needs_input_grad[1] else None
-        g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        g_w, g_b = _weight_and_bias_grad(g, x, ctx.needs_input_grad[1],
+                                         ctx.has_bias and ctx.needs_input_grad[2], dy_first=True)
         return g_x, g_w, g_b
 
 
@@ -732,16 +755,18 @@ class GruCell(torch.autograd.Function):
                      "spmi_gru_gate_bwd")
         h_old = saved[:, 4 * hd:]
         g_x = g_gi @ w_ih if ctx.needs_input_grad[0] else None
-        g_wih = gemm_tn(g_gi, xd) if ctx.needs_input_grad[1] else None
-        g_whh = gemm_tn(g_gh, h_old) if ctx.needs_input_grad[2] else None
-        g_bih = g_bhh = None
-        if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            # the r and z columns of g_gi and g_gh are the same numbers: sum them once
-            g_bih = g_gi.sum(0)
-            if ctx.needs_input_grad[4]:
-                g_bhh = torch.cat([g_bih[: 2 * hd], g_gh[:, 2 * hd:].sum(0)])
-            if not ctx.needs_input_grad[3]:
-                g_bih = None
+        need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        need_bhh = ctx.has_bias and ctx.needs_input_grad[4]
+        # bias gradients = column sums of the gate gradients, taken by the weight-gradient
+        # kernels on their way through g_gi / g_gh
+        g_wih, g_bih = _weight_and_bias_grad(g_gi, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
+        g_whh, s_gh = _weight_and_bias_grad(g_gh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
+        g_bhh = None
+        if need_bhh:
+            # the r and z columns of g_gi and g_gh are the same numbers
+            g_bhh = torch.cat([g_bih[: 2 * hd], s_gh[2 * hd:]])
+        if not (ctx.has_bias and ctx.needs_input_grad[3]):
+            g_bih = None
         return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
 
 
@@ -785,9 +810,9 @@ class LstmCell(torch.autograd.Function):
                                                  nv.ptr(g_g), None, nv.stream()),
                      "spmi_lstm_gate_bwd")
         g_x = g_g @ w_ih if ctx.needs_input_grad[0] else None
-        g_wih = gemm_tn(g_g, xd) if ctx.needs_input_grad[1] else None
+        need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        g_wih, g_b = _weight_and_bias_grad(g_g, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
         g_whh = gemm_tn(g_g, h_old) if ctx.needs_input_grad[2] else None
-        g_b = g_g.sum(0) if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         return g_x, g_wih, g_whh, g_b, g_b, None, None, None, None
 
 
@@ -826,9 +851,9 @@ class RnnCell(torch.autograd.Function):
             nv.check(nv.lib().spmi_rnn_gate_bwd(nv.ptr(g_h), nv.ptr(h_out), m, hd, nv.ptr(g_g),
                                                 nv.stream()), "spmi_rnn_gate_bwd")
         g_x = g_g @ w_ih if ctx.needs_input_grad[0] else None
-        g_wih = gemm_tn(g_g, xd) if ctx.needs_input_grad[1] else None
+        need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        g_wih, g_b = _weight_and_bias_grad(g_g, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
         g_whh = gemm_tn(g_g, h_old) if ctx.needs_input_grad[2] else None
-        g_b = g_g.sum(0) if ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) else None
         return g_x, g_wih, g_whh, g_b, g_b, None, None, None
 
 
@@ -871,10 +896,10 @@ class GruCellDense(torch.autograd.Function):
         h_old = saved[:, 4 * hd:]
         g_x = g_gi @ w_ih if ctx.needs_input_grad[0] else None
         g_h = g_hd + g_gh @ w_hh if ctx.needs_input_grad[1] else None
-        g_wih = gemm_tn(g_gi, xd) if ctx.needs_input_grad[2] else None
-        g_whh = gemm_tn(g_gh, h_old) if ctx.needs_input_grad[3] else None
-        g_bih = g_gi.sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
-        g_bhh = g_gh.sum(0) if ctx.has_bias and ctx.needs_input_grad[5] else None
+        g_wih, g_bih = _weight_and_bias_grad(g_gi, xd, ctx.needs_input_grad[2],
+                                             ctx.has_bias and ctx.needs_input_grad[4], dy_first=True)
+        g_whh, g_bhh = _weight_and_bias_grad(g_gh, h_old, ctx.needs_input_grad[3],
+                                             ctx.has_bias and ctx.needs_input_grad[5], dy_first=True)
         return g_x, g_h, g_wih, g_whh, g_bih, g_bhh
 
 

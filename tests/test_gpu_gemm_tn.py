@@ -70,3 +70,24 @@ def test_dense_layers_use_it_and_keep_their_gradients(dev):
     (ops.rows_times_weight(x, wa) * wgt).sum().backward()
     ((x @ wb) * wgt).sum().backward()
     assert rel(wa.grad, wb.grad) < 1e-5
+
+
+@pytest.mark.parametrize("k,m,n", [(20001, 128, 384), (50_000, 10, 128), (16_400, 33, 65), (100_000, 384, 128),
+                                   (17_000, 5, 1)])
+def test_operand_column_sums_ride_along(dev, k, m, n):
+    """spmi_gemm_tn_sums: the column sums of A and of B from the same pass (bias gradients next
+    to weight gradients), float64 reference, 1e-5 relative to the sum of absolute terms, fixed
+    order; the product is unchanged bit for bit."""
+    rng = np.random.default_rng(k + m)
+    a = (rng.standard_normal((k, m)) + 0.3).astype(np.float32)
+    b = (rng.standard_normal((k, n)) - 0.2).astype(np.float32)
+    at, bt = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    got, sa, sb = ops.gemm_tn(at, bt, sum_a=True, sum_b=True)
+    assert torch.equal(got, ops.gemm_tn(at, bt))
+    for s, ref in ((sa, a), (sb, b)):
+        want = ref.astype(np.float64).sum(0)
+        scale = np.abs(ref).astype(np.float64).sum(0)
+        assert s.shape == want.shape
+        assert (np.abs(s.cpu().numpy() - want) / scale).max() < 1e-5
+    _, sa2, _ = ops.gemm_tn(at, bt, sum_a=True)
+    assert torch.equal(sa, sa2)
