@@ -425,11 +425,17 @@ int spmi_gemm_tn(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/
  * next to dW = X^T dY: the autograd of `+ bias` in dgl GraphConv.forward, nn.GRU/LSTM/RNN and
  * nn.Linear, same reference lines as spmi_gemm_tn), so the sum costs one add per element
  * already in a register instead of another pass over a [nodes, width] matrix.  Fixed
- * summation order (bit-reproducible).  Workspace as for spmi_gemm_tn. */
+ * summation order (bit-reproducible).  Workspace as for spmi_gemm_tn.
+ * fp32_instruction != 0: products on the fp32 matrix instruction, as spmi_gemm_tn.
+ * fp32_instruction == 0: products on the bf16 matrix cores at fp32 accuracy: every operand
+ * value is split exactly into three bf16 pieces and a product is summed from the six piece
+ * products above 2^-24 of its size, fp32 accumulation; no range limit beyond bfloat16's own
+ * (fp32's exponent range); 2-3x faster on these shapes (HBM-bound instead of matrix-bound). */
 int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/, int64_t ldb,
                       int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc,
                       int accumulate, float* col_sum_a /*nullable [M]*/,
-                      float* col_sum_b /*nullable [N]*/, void* ws, size_t ws_bytes, void* stream);
+                      float* col_sum_b /*nullable [N]*/, int fp32_instruction, void* ws,
+                      size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Output head in inference, one kernel: the MLP of

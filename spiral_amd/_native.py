@@ -83,7 +83,7 @@ _SIGNATURES = {
     "spmi_gemm_tn": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_int, c_vp,
                              c_sz, c_vp]),
     "spmi_gemm_tn_sums": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_int, c_vp,
-                                  c_vp, c_vp, c_sz, c_vp]),
+                                  c_vp, c_int, c_vp, c_sz, c_vp]),
     "spmi_mlp_head_supported": (c_int, [c_i64, c_i32, c_i32, c_vp]),
     "spmi_mlp_head_fwd": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
                                   c_vp, c_i32, c_vp, c_i64, c_vp]),

@@ -19,6 +19,8 @@
 // no atomics.  Exact fp32 products and fp32 accumulation (not a reduced-precision format).
 // Bound: MFMA for wide outputs (2*K*M*N flop), HBM (K*(M+N)*4 bytes) for narrow ones.
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -131,6 +133,181 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_partial_kernel(
   }
 }
 
+// The same block product on the bf16 matrix cores at fp32 accuracy: every fp32 operand value is
+// split exactly into three bf16 pieces (v = hi + mid + lo) and a product is summed from the six
+// piece products down to 2^-24 of its size (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid), with
+// fp32 accumulation.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) stand where eight
+// v_mfma_f32_32x32x2_f32 (64 cycles, K = 2) stood: 2.7x less matrix time, which moves these
+// shapes from the fp32 matrix peak to the HBM stream of their operands.  A wave owns a
+// (32 MT) x (32 NT) block of C, so a split piece of A feeds NT products and one of B feeds MT.
+// Operand layout of the K = 16 instruction: lane l holds eight consecutive k of column l % 32,
+// k = 8 (l / 32) + i: eight loads per operand column, each two coalesced 128-byte row segments,
+// as before.  The loads of the next sixteen rows are issued before the current ones are split.
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3x8(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = static_cast<__bf16>(v[i]);
+    const float r1 = v[i] - static_cast<float>(h);
+    const __bf16 m = static_cast<__bf16>(r1);
+    hi[i] = h;
+    mid[i] = m;
+    lo[i] = static_cast<__bf16>(r1 - static_cast<float>(m));
+  }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_partial_x3_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
+    int M, int N, int64_t k_chunk, float* __restrict__ partial, int m_groups, int n_tiles,
+    float* __restrict__ sum_a_partial, float* __restrict__ sum_b_partial) {
+  const int lane = threadIdx.x & 63;
+  const int st = static_cast<int>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  if (st >= m_groups * n_tiles) return;
+  const int m0 = (st % m_groups) * 32 * MT;
+  const int n0 = (st / m_groups) * 32 * NT;
+  const int64_t k_begin = static_cast<int64_t>(blockIdx.y) * k_chunk;
+  const int64_t k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  bool a_ok[MT], b_ok[NT];
+  uint32_t a_off[MT], b_off[NT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    a_ok[s] = m0 + 32 * s + lr < M;
+    a_off[s] = static_cast<uint32_t>(lh * 8 * lda + (a_ok[s] ? m0 + 32 * s + lr : 0));
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    b_ok[t] = n0 + 32 * t + lr < N;
+    b_off[t] = static_cast<uint32_t>(lh * 8 * ldb + (b_ok[t] ? n0 + 32 * t + lr : 0));
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.0f;
+  const bool want_sa = sum_a_partial != nullptr && n0 == 0;
+  const bool want_sb = sum_b_partial != nullptr && m0 == 0;
+  float sa[MT], sb[NT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) sa[s] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sb[t] = 0.0f;
+
+  // Rows past the chunk's end are read from its last row (valid memory) and zeroed.
+  float a[MT][8], b[NT][8];
+  // FULL: all sixteen rows of the step lie inside the chunk (every step but the last): row
+  // bases are wave-uniform scalars and nothing is masked by row.
+  auto load = [&](auto full_tag, int64_t k, float (&av)[MT][8], float (&bv)[NT][8]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int64_t row = k + u;  // this lane reads row + 8 lh (the lane half is in the offsets)
+      if constexpr (!FULL) {
+        const int64_t last = k_end - 1 - 8 * lh;
+        row = row > last ? last : row;
+      }
+      const float* a_row = A + row * lda;
+      const float* b_row = B + row * ldb;
+#pragma unroll
+      for (int s = 0; s < MT; ++s) av[s][u] = a_row[a_off[s]];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t][u] = b_row[b_off[t]];
+    }
+  };
+  auto step = [&](auto full_tag, int64_t k, float (&av)[MT][8], float (&bv)[NT][8]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bool ok = a_ok[s];
+        if constexpr (!FULL) ok = ok && (k + 8 * lh + u < k_end);
+        av[s][u] = ok ? av[s][u] : 0.0f;
+        sa[s] += av[s][u];
+      }
+      split3x8(av[s], ah[s], am[s], al[s]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bool ok = b_ok[t];
+        if constexpr (!FULL) ok = ok && (k + 8 * lh + u < k_end);
+        bv[t][u] = ok ? bv[t][u] : 0.0f;
+        sb[t] += bv[t][u];
+      }
+      split3x8(bv[t], bh[t], bm[t], bl[t]);
+    }
+#pragma unroll
+    for (int s = 0; s < MT; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {  // smallest terms first
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bm[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bh[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bm[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[t], acc[s][t], 0, 0, 0);
+      }
+  };
+
+  // full steps two at a time with the loads of the step after next in flight; k_chunk is a
+  // multiple of 16, so only the last chunk of K can end in a partial step
+  float a2[MT][8], b2[NT][8];
+  const int64_t n_full = (k_end - k_begin) / 16;
+  int64_t k = k_begin;
+  int64_t i = 0;
+  if (n_full > 0) load(std::true_type{}, k, a, b);
+  for (; i + 2 <= n_full; i += 2, k += 32) {
+    load(std::true_type{}, k + 16, a2, b2);
+    step(std::true_type{}, k, a, b);
+    if (i + 2 < n_full) load(std::true_type{}, k + 32, a, b);
+    step(std::true_type{}, k + 16, a2, b2);
+  }
+  if (i < n_full) {
+    step(std::true_type{}, k, a, b);
+    k += 16;
+  }
+  if (k < k_end) {
+    load(std::false_type{}, k, a, b);
+    step(std::false_type{}, k, a, b);
+  }
+
+  if (want_sa) {
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const float v = sa[s] + __shfl_xor(sa[s], 32);
+      if (lh == 0 && a_ok[s]) sum_a_partial[static_cast<size_t>(blockIdx.y) * M + m0 + 32 * s + lr] = v;
+    }
+  }
+  if (want_sb) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float v = sb[t] + __shfl_xor(sb[t], 32);
+      if (lh == 0 && b_ok[t]) sum_b_partial[static_cast<size_t>(blockIdx.y) * N + n0 + 32 * t + lr] = v;
+    }
+  }
+  float* out = partial + static_cast<size_t>(blockIdx.y) * M * N;
+#pragma unroll
+  for (int s = 0; s < MT; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 32 * t + lr;
+      if (n >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + 32 * s + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < M) out[static_cast<size_t>(m) * N + n] = acc[s][t][e];
+      }
+    }
+}
+
 // C = (accumulate ? C : 0) + sum over chunks.  L lanes share one output element: lane c of
 // the group adds chunks c, c+L, ... and the group is folded by a shuffle tree, so the order
 // of additions is fixed by the shape alone.  Inside a wave the 64/L elements are the fast
@@ -164,6 +341,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_reduce_kernel(const float* _
 }
 
 struct Shape {
+  int mt;         // 32-row strips per wave (bf16-piece kernel only)
   int nt;         // 32-column tiles per wave
   int m_strips;   // ceil(M / 32)
   int n_tiles;    // ceil(N / (32 * nt))
@@ -171,10 +349,11 @@ struct Shape {
   int64_t k_chunk;
 };
 
-Shape plan(int64_t M, int64_t N, int64_t K) {
+Shape plan(int64_t M, int64_t N, int64_t K, bool pieces) {
   Shape s{};
-  s.nt = N > 64 ? 4 : (N > 32 ? 2 : 1);
-  s.m_strips = static_cast<int>((M + 31) / 32);
+  s.mt = (pieces && M > 32) ? 2 : 1;
+  s.nt = pieces ? (N > 32 ? 2 : 1) : (N > 64 ? 4 : (N > 32 ? 2 : 1));
+  s.m_strips = static_cast<int>((M + 32 * s.mt - 1) / (32 * s.mt));
   s.n_tiles = static_cast<int>((N + 32 * s.nt - 1) / (32 * s.nt));
   const int64_t blocks = s.m_strips * s.n_tiles;
   // about eight waves per SIMD over the whole chip, at least 256 rows of K per wave
@@ -200,20 +379,23 @@ extern "C" {
 
 size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || M > 4096 || N > 4096) return 0;
-  const Shape s = plan(M, N, K);
-  return sizeof(float) * static_cast<size_t>(s.n_chunks) * (M * N + M + N);
+  // the two kernels cut K differently: room for the finer cut
+  const Shape s0 = plan(M, N, K, false), s1 = plan(M, N, K, true);
+  const int chunks = s0.n_chunks > s1.n_chunks ? s0.n_chunks : s1.n_chunks;
+  return sizeof(float) * static_cast<size_t>(chunks) * (M * N + M + N);
 }
 
 int spmi_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t M,
                  int64_t N, float* C, int64_t ldc, int accumulate, void* ws, size_t ws_bytes,
                  void* stream) {
-  return spmi_gemm_tn_sums(A, lda, B, ldb, K, M, N, C, ldc, accumulate, nullptr, nullptr, ws, ws_bytes,
-                           stream);
+  return spmi_gemm_tn_sums(A, lda, B, ldb, K, M, N, C, ldc, accumulate, nullptr, nullptr, 1, ws,
+                           ws_bytes, stream);
 }
 
 int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int64_t M,
                       int64_t N, float* C, int64_t ldc, int accumulate, float* col_sum_a,
-                      float* col_sum_b, void* ws, size_t ws_bytes, void* stream) {
+                      float* col_sum_b, int fp32_instruction, void* ws, size_t ws_bytes,
+                      void* stream) {
   if (int rc = check_gemm_tn(M, N, K)) return rc;
   SPMI_REQUIRE(A && B && C && ws, SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: null pointer argument");
   SPMI_REQUIRE(lda >= M && ldb >= N && ldc >= N, SPMI_ERR_INVALID_ARG,
@@ -222,7 +404,10 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
   SPMI_REQUIRE(ws_bytes >= spmi_gemm_tn_workspace_bytes(M, N, K), SPMI_ERR_WORKSPACE,
                "spmi_gemm_tn: workspace %zu < required %zu", ws_bytes,
                spmi_gemm_tn_workspace_bytes(M, N, K));
-  const Shape s = plan(M, N, K);
+  const bool pieces = fp32_instruction == 0;
+  const Shape s = plan(M, N, K, pieces);
+  SPMI_REQUIRE(lda < (int64_t{1} << 27) && ldb < (int64_t{1} << 27), SPMI_ERR_UNSUPPORTED,
+               "spmi_gemm_tn: leading dimension too large");
   hipStream_t st = spmi::as_stream(stream);
   float* partial = static_cast<float*>(ws);
   float* pa = col_sum_a ? partial + static_cast<size_t>(s.n_chunks) * M * N : nullptr;
@@ -231,10 +416,20 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
 #define SPMI_GEMM_TN(NT)                                                                        \
   gemm_tn_partial_kernel<NT><<<grid, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N,     \
                                                         s.k_chunk, partial, s.m_strips, s.n_tiles, pa, pb)
-  if (s.nt == 4) SPMI_GEMM_TN(4);
+#define SPMI_GEMM_TN_X3(MT, NT)                                                                   \
+  gemm_tn_partial_x3_kernel<MT, NT><<<grid, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N, \
+                                                               s.k_chunk, partial, s.m_strips,   \
+                                                               s.n_tiles, pa, pb)
+  if (pieces) {
+    if (s.mt == 2 && s.nt == 2) SPMI_GEMM_TN_X3(2, 2);
+    else if (s.mt == 2) SPMI_GEMM_TN_X3(2, 1);
+    else if (s.nt == 2) SPMI_GEMM_TN_X3(1, 2);
+    else SPMI_GEMM_TN_X3(1, 1);
+  } else if (s.nt == 4) SPMI_GEMM_TN(4);
   else if (s.nt == 2) SPMI_GEMM_TN(2);
   else SPMI_GEMM_TN(1);
 #undef SPMI_GEMM_TN
+#undef SPMI_GEMM_TN_X3
   SPMI_CHECK_LAUNCH("gemm_tn_partial");
   const int64_t mn = M * N;
   if (s.n_chunks >= 64) {

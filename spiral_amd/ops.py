@@ -89,6 +89,10 @@ def gcn_aggregate(g, x: torch.Tensor, norm: str = "both", bias: Optional[torch.T
 
 # --------------------------------------------------------------------------- dense layers
 GEMM_TN_MIN_ROWS = 16384  # below this many rows the library GEMM is as good
+# How spmi_gemm_tn multiplies: "bf16x3" = operands split exactly into three bf16 pieces, six piece
+# products per term on the bf16 matrix cores (fp32-accurate, no range limit, 2-3x faster);
+# "fp32" = the fp32 matrix instruction.
+GEMM_TN_MODE = "bf16x3"
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, sum_a: bool = False, sum_b: bool = False):
@@ -114,8 +118,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, sum_a: bool = False, sum_b: bool =
         ws_bytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         nv.check(lib.spmi_gemm_tn_sums(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n,
-                                       nv.ptr(out), n, 0, nv.ptr(sa), nv.ptr(sb), nv.ptr(ws), ws_bytes,
-                                       nv.stream()), "spmi_gemm_tn_sums")
+                                       nv.ptr(out), n, 0, nv.ptr(sa), nv.ptr(sb), int(GEMM_TN_MODE == "fp32"),
+                                       nv.ptr(ws), ws_bytes, nv.stream()), "spmi_gemm_tn_sums")
     return (out, sa, sb) if sums else out
 
 

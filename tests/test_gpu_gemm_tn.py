@@ -1,5 +1,6 @@
-"""The weight-gradient GEMM C = A^T B (split-K on the fp32 matrix cores) against float64
-numpy: fp32 products and sums, so 1e-5 relative to the sum of absolute terms."""
+"""The weight-gradient GEMM C = A^T B (split-K on the matrix cores; products from exact bf16
+pieces or on the fp32 instruction) against float64 numpy: fp32-accurate products and fp32
+sums, so 1e-5 relative to the sum of absolute terms."""
 import numpy as np
 import pytest
 import torch
@@ -14,7 +15,9 @@ pytestmark = pytest.mark.gpu
     (16384, 128, 128), (20001, 128, 384), (50_000, 10, 128), (33_333, 20, 10), (17_000, 5, 1),
     (16_400, 33, 65), (100_000, 256, 512), (16385, 1, 1),
 ])
-def test_gemm_tn_matches_float64(dev, k, m, n):
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_gemm_tn_matches_float64(dev, k, m, n, mode, monkeypatch):
+    monkeypatch.setattr(ops, "GEMM_TN_MODE", mode)
     rng = np.random.default_rng(k + m + n)
     a = rng.standard_normal((k, m)).astype(np.float32)
     b = rng.standard_normal((k, n)).astype(np.float32)
@@ -91,3 +94,24 @@ def test_operand_column_sums_ride_along(dev, k, m, n):
         assert (np.abs(s.cpu().numpy() - want) / scale).max() < 1e-5
     _, sa2, _ = ops.gemm_tn(at, bt, sum_a=True)
     assert torch.equal(sa, sa2)
+
+
+def test_bf16_pieces_keep_fp32_range_and_accuracy(dev):
+    """Operands of very different magnitudes (gradients of a mean loss over a million rows are
+    1e-6 and smaller): the bf16-piece products carry no range limit and are as close to float64
+    as the fp32 instruction's."""
+    k, m, n = 60_000, 96, 64
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((k, m)) * np.exp(rng.uniform(-30, 5, (k, 1)))).astype(np.float32)
+    b = (rng.standard_normal((k, n)) * 1e-7).astype(np.float32)
+    at, bt = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+    errs = {}
+    for mode in ("bf16x3", "fp32"):
+        old, ops.GEMM_TN_MODE = ops.GEMM_TN_MODE, mode
+        try:
+            errs[mode] = (np.abs(ops.gemm_tn(at, bt).cpu().numpy() - want) / scale).max()
+        finally:
+            ops.GEMM_TN_MODE = old
+    assert errs["bf16x3"] < 1e-5 and errs["bf16x3"] < 4 * errs["fp32"] + 1e-7, errs
