@@ -444,6 +444,7 @@ def main():
     def front(t, ev):
         src, dst = snapshots[t % n_snap]
         shard = par.ShardedSnapshot(src, dst, part, group=deg_group, stages=n_stages)
+        shard.global_view().csr()  # first, with edge positions: the same grouping then serves layer 2
         shard.batch_csrs()
         shard.norm("in", 0)
         shard.norm_global(0)

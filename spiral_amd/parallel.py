@@ -99,8 +99,14 @@ class ExchangePlan:
     id order.  `columns` gives every edge its row of that table.  Building the plan costs two
     small all-to-alls (counts, then the requested row numbers) and two host round trips."""
 
-    def __init__(self, src: torch.Tensor, part: RowPartition, group=None, stages: int = 1):
+    def __init__(self, src: torch.Tensor, part: RowPartition, group=None, stages: int = 1,
+                 data_group=None):
+        """`group`: communicator of the plan's own small collectives; `data_group`: communicator
+        of the row exchanges.  A caller that keeps the exchange of one snapshot in flight while
+        it builds the plan of the next passes two different ones, so that the small messages do
+        not queue behind the rows (collectives of one communicator run in order)."""
         self.part, self.group, self.stages = part, group, max(int(stages), 1)
+        self.data_group = data_group
         dev = src.device
         world, rank = part.world, part.rank
         lo, hi = part.block()
@@ -227,7 +233,7 @@ def exchange_rows_async(z_local: torch.Tensor, plan: ExchangePlan,
             out = table[plan.batch_start[k]: plan.batch_start[k + 1]]
             inp = send[plan.send_batch_start[k]: plan.send_batch_start[k + 1]]
             works.append(dist.all_to_all_single(out, inp, plan.recv_counts[k], plan.send_counts[k],
-                                                group=plan.group, async_op=True))
+                                                group=plan.data_group, async_op=True))
     else:
         works = [None] * plan.stages
     return PendingTable(table, works, send, prescaled)
@@ -247,7 +253,7 @@ def _return_rows(g_table: torch.Tensor, plan: ExchangePlan) -> torch.Tensor:
     for k in range(plan.stages):
         inp = g_table[plan.batch_start[k]: plan.batch_start[k + 1]].contiguous()
         out = back[plan.send_batch_start[k]: plan.send_batch_start[k + 1]]
-        dist.all_to_all_single(out, inp, plan.send_counts[k], plan.recv_counts[k], group=plan.group)
+        dist.all_to_all_single(out, inp, plan.send_counts[k], plan.recv_counts[k], group=plan.data_group)
     off = 0
     for k in range(plan.stages):
         for p in range(plan.part.world):
@@ -270,13 +276,15 @@ class ShardedSnapshot(G.NormalisedAdjacency):
     sources renumbered to rows of the compact source table of the exchange plan."""
 
     def __init__(self, src: torch.Tensor, dst: torch.Tensor, part: RowPartition, group=None,
-                 stages: int = 1):
-        """src/dst: the edges whose destination lies in this rank's block (global ids)."""
+                 stages: int = 1, data_group=None):
+        """src/dst: the edges whose destination lies in this rank's block (global ids).
+        `group` carries the per-snapshot bookkeeping (plan, out-degrees), `data_group` the row
+        exchanges (see ExchangePlan)."""
         self.part, self.group = part, group
         lo, hi = part.block()
         self.n_local = hi - lo
         self.src_global = src.to(torch.int64)
-        self.plan = ExchangePlan(self.src_global, part, group, stages)
+        self.plan = ExchangePlan(self.src_global, part, group, stages, data_group)
         self.cols = self.plan.columns(self.src_global)
         self.dst_rows = dst.to(torch.int64) - lo
         self._csr = self._csr_t = self._batch_csrs = self._global = None
@@ -284,11 +292,12 @@ class ShardedSnapshot(G.NormalisedAdjacency):
         self._norms = {}
 
     @classmethod
-    def from_global(cls, src, dst, part: RowPartition, group=None, stages: int = 1) -> "ShardedSnapshot":
+    def from_global(cls, src, dst, part: RowPartition, group=None, stages: int = 1,
+                    data_group=None) -> "ShardedSnapshot":
         """Keep the edges of a full edge list that end in this rank's block."""
         lo, hi = part.block()
         keep = (dst >= lo) & (dst < hi)
-        return cls(src[keep], dst[keep], part, group, stages)
+        return cls(src[keep], dst[keep], part, group, stages, data_group)
 
     def csr(self, want_eid: bool = False, wait: bool = True):
         if self._csr is None or (want_eid and self._csr.eid is None):
