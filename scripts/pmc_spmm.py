@@ -20,8 +20,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from spiral_amd import graph as G  # noqa: E402
 from perf_spmm import powerlaw  # noqa: E402
 
+# usage: pmc_spmm.py [F] [k_dst]   (defaults 128, 3.0: the headline workload)
+f = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+k_dst = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 dev = torch.device("cuda:0")
-n_cal, f = 10_000_000, 128
+n_cal = 10_000_000 if f <= 128 else 5_000_000
 perm = torch.randperm(n_cal, device=dev)
 rows = torch.arange(n_cal, device=dev)
 csr_cal = G.build_csr(rows, perm, n_cal, n_cal)
@@ -31,7 +34,7 @@ ew_cal = torch.ones(n_cal, device=dev)
 ds_cal = torch.ones(n_cal, device=dev)
 
 n, e = 1_000_000, 10_000_000
-src, dst = powerlaw(n, e, 0, 3.0, 1.5, dev)
+src, dst = powerlaw(n, e, 0, k_dst, 1.5, dev)
 csr = G.build_csr(dst, src, n, n)
 csr_t = G.build_csr(src, dst, n, n)
 x = torch.randn(n, f, device=dev)

@@ -1,7 +1,7 @@
 """profiles/r01_spmm_traffic.json from two `rocprofv3 --pmc` passes over scripts/pmc_spmm.py
 (FETCH_SIZE in one run, WRITE_SIZE in another):
 
-    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag]
+    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag] [workload] [F]
 
 Launch groups alternate calibration / benchmark (three repetitions); a group is the stream
 kernel plus, when the graph has hub rows, the two heavy-row kernels.  The read counter is
@@ -11,7 +11,10 @@ import json
 import os
 import sys
 
-N_CAL, N, E, F = 10_000_000, 1_000_000, 10_000_000, 128
+N, E = 1_000_000, 10_000_000
+WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "config2"
+F = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+N_CAL = 10_000_000 if F <= 128 else 5_000_000
 
 
 def groups(path, counter):
@@ -38,9 +41,9 @@ def main():
     rf, wf = known_r / cal_r, known_w / cal_w
     algorithmic = E * (F * 4 + 4) + (N + 1) * 4 + 2 * N * 4 + N * F * 4 + F * 4
     doc = {
-        "workload": "config2: 1M nodes x 10M edges, F=128, inference launch (no per-edge weight, destination "
+        "workload": f"{WORKLOAD}: 1M nodes x 10M edges, F={F}, inference launch (no per-edge weight, destination "
                     "scale + bias + leaky_relu fused), fp32",
-        "calibration": {"graph": "permutation graph, 10M rows, one neighbour each (every source row read once)",
+        "calibration": {"graph": f"permutation graph, {N_CAL} rows, one neighbour each (every source row read once)",
                         "known_read_bytes": known_r, "fetch_size_bytes_raw": cal_r, "read_factor": rf,
                         "known_write_bytes": known_w, "write_size_bytes_raw": cal_w, "write_factor": wf},
         "read_bytes_per_launch": ben_r * rf,
@@ -51,7 +54,7 @@ def main():
                 "counter is scaled by the factor that makes the calibration launch match its known traffic",
     }
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                       f"{sys.argv[3] if len(sys.argv) > 3 else 'rXX'}_spmm_traffic.json")
+                       f"{sys.argv[3] if len(sys.argv) > 3 else 'rXX'}_{WORKLOAD}_spmm_traffic.json")
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(doc, indent=1))
