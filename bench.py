@@ -53,7 +53,7 @@ HEAD_DIMS = [10, 20, 10, 5]  # the MLP of examples/torch/citation_prediction.py:
 CPU_SAMPLE_DIV = 4      # the CPU baseline runs a snapshot of 1/4 of the nodes and edges
 
 
-def measured_traffic(workload: str, world: int):
+def measured_traffic(workload: str, world: int, widths=None):
     """HBM-side bytes per fused-aggregation launch group from the committed rocprofv3 PMC runs
     of the same workload and kernel (FETCH_SIZE / WRITE_SIZE in separate passes, read side
     calibrated on a copy of known size: profiles/*_spmm_traffic.json, newest first).  Counters
@@ -65,8 +65,11 @@ def measured_traffic(workload: str, world: int):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_spmm_traffic.json")), reverse=True):
         with open(path) as fh:
             rec = json.load(fh)
-        if rec.get("workload", "config2").split(":")[0].strip() == workload:
-            return rec["traffic_bytes_per_launch"]
+        if rec.get("workload", "config2").split(":")[0].strip() != workload:
+            continue
+        if widths is not None and widths != [rec.get("feature_width", 128)]:
+            continue  # the record prices one width; this run's launches mix several
+        return rec["traffic_bytes_per_launch"]
     return None
 
 
@@ -665,7 +668,7 @@ def main():
             "stages": stages,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world, widths),
                 "kernel": "; ".join(aggregation_kernel_name(fw, kind == "evolve_bf16") for fw in widths),
                 "feature_widths": widths,
                 "avg_launch_ms": spmm_avg_ms, "launches": len(spmm_ms),

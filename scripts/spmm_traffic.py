@@ -43,6 +43,7 @@ def main():
     doc = {
         "workload": f"{WORKLOAD}: 1M nodes x 10M edges, F={F}, inference launch (no per-edge weight, destination "
                     "scale + bias + leaky_relu fused), fp32",
+        "feature_width": F,
         "calibration": {"graph": f"permutation graph, {N_CAL} rows, one neighbour each (every source row read once)",
                         "known_read_bytes": known_r, "fetch_size_bytes_raw": cal_r, "read_factor": rf,
                         "known_write_bytes": known_w, "write_size_bytes_raw": cal_w, "write_factor": wf},
