@@ -347,8 +347,9 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
  * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].
  * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites
  * staticGraphEncoder.py:113,116; likewise SGConv / SAGEConv's fc layers) and the Linear
- * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} and
- * N in {32, 64, 96, 128}.  fp32 results from the fp16 matrix cores with the three-plane
+ * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} with
+ * N in {32, 64, 96, 128} or any multiple of 128, and K = 256 with N a multiple of 64 (wide
+ * outputs are computed in column slices by workgroups that share an XCD's L2).  fp32 results from the fp16 matrix cores with the three-plane
  * operand format of spmi_cell_f16x3_fwd (same accuracy).  The rows of x may hold any finite
  * fp32 value (each row is scaled by a power of two before it is split and its results by the
  * inverse; a non-finite entry makes its own row non-finite); |W| <= 1023;

@@ -23,7 +23,11 @@
 //    (K/2 VGPRs); as soon as the slice of K-step t is split, the same registers receive the
 //    K-step t of the wave's next tile, so 16 KB per wave (128 KB per CU) are in flight while
 //    the matrix cores work;
-//  * waves are independent after the weight load: no barrier in the loop.
+//  * waves are independent after the weight load: no barrier in the loop;
+//  * wide outputs (N > 128) and K = 256 are cut into column slices of 128 (64 for K = 256)
+//    that fit LDS: the workgroups that hold the slices of one row range run on one XCD
+//    (blockIdx -> XCD is round-robin) and walk the same tiles, so the rows they all read
+//    come from HBM once and from that XCD's L2 afterwards.
 
 #include "common.h"
 
@@ -43,6 +47,8 @@ struct RowsArgs {
   float slope;
   float* out;
   int64_t ldo;
+  int n_total;  // columns of the whole weight; a workgroup computes NB * 32 of them
+  int slices;   // n_total / (NB * 32)
 };
 
 __device__ __forceinline__ void split8(const float4& lo, const float4& hi, f16x8& p0, f16x8& p1,
@@ -58,7 +64,10 @@ __device__ __forceinline__ void split8(const float4& lo, const float4& hi, f16x8
 }
 
 template <int KT, int NB>
-__global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
+__global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_kernel(RowsArgs p) {
+  // K = 256 keeps 128 registers of row data per lane: four waves per workgroup, one per SIMD,
+  // with the whole register file; the smaller shapes run eight waves (two per SIMD).
+  constexpr int NW = KT > 8 ? 4 : 8;
   constexpr int N = NB * 32;
   constexpr int PLANE = N * 32;           // bytes of one plane of one K-step
   constexpr int KSTEP = 3 * PLANE;        // bytes of one K-step
@@ -66,8 +75,19 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
   extern __shared__ uint4 smem4[];
   const char* smem = reinterpret_cast<const char*>(smem4);
 
+  // Workgroup b runs on XCD b % 8; the column slices of one row group sit on one XCD.
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.slices;
+  const int group = (b & 7) + 8 * (b / (8 * p.slices));
+  const int n_groups = gridDim.x / p.slices;
+  const int col0 = slice * N;
+
   const int tid = threadIdx.x;
-  for (int c = tid; c < B16; c += 512) smem4[c] = p.wp[c];
+  // image [K-step][plane][k half][n_total][8]: 16-byte chunk index ((t*3+q)*2+h) * n_total + n
+  for (int c = tid; c < B16; c += NW * 64) {
+    const int n = c % N, rest = c / N;
+    smem4[c] = p.wp[static_cast<size_t>(rest) * p.n_total + col0 + n];
+  }
   __syncthreads();
 
   const int lane = tid & 63;
@@ -75,13 +95,13 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
   const int lr = lane & 31;
   const int lh = lane >> 5;
   const int64_t n_tiles = (p.M + 31) / 32;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * 8;
-  int64_t tile = static_cast<int64_t>(blockIdx.x) * 8 + wave;
+  const int64_t stride = static_cast<int64_t>(n_groups) * NW;
+  int64_t tile = static_cast<int64_t>(group) * NW + wave;
   if (tile >= n_tiles) return;
 
   float bias[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bias[nb] = p.bias ? p.bias[nb * 32 + lr] : 0.0f;
+  for (int nb = 0; nb < NB; ++nb) bias[nb] = p.bias ? p.bias[col0 + nb * 32 + lr] : 0.0f;
 
   // Rows past M are clamped to the last row: computed, never stored.
   auto row_ptr = [&](int64_t t) {
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_kernel(RowsArgs p) {
     // C layout of the 32x32 MFMA: element e of lane l is row (e&3) + 8 (e>>2) + 4 (l>>5),
     // column l&31: a store covers two 128-byte row segments.
     const int64_t row0 = tile * 32;
-    float* obase = p.out + row0 * p.ldo;  // wave-uniform
+    float* obase = p.out + row0 * p.ldo + col0;  // wave-uniform
     const int voff = 4 * lh * static_cast<int>(p.ldo) + lr;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -205,21 +225,40 @@ int launch(const RowsArgs& a, hipStream_t st) {
     configured = true;
   }
   const int64_t n_tiles = (a.M + 31) / 32;
-  const int64_t wgs = (n_tiles + 7) / 8;
-  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-  const int64_t cap = 256 * per_cu;
-  kern<<<static_cast<unsigned>(wgs < cap ? wgs : cap), 512, lds, st>>>(a);
+  const int per_cu = (lds * 2 <= 160 * 1024 && KT <= 8) ? 2 : 1;
+  // row groups of NW tiles, in whole sets of 8 XCDs; every group has `slices` workgroups
+  constexpr int NW = KT > 8 ? 4 : 8;
+  int64_t sets = (n_tiles + 8 * NW - 1) / (8 * NW);
+  int64_t max_sets = 256 * per_cu / (8 * a.slices);
+  if (max_sets < 1) max_sets = 1;
+  if (sets > max_sets) sets = max_sets;
+  kern<<<static_cast<unsigned>(sets * 8 * a.slices), NW * 64, lds, st>>>(a);
   SPMI_CHECK_LAUNCH("gemm_rows");
   return SPMI_OK;
 }
 
+// Columns per workgroup: the whole weight up to 128 columns, slices of 128 (K <= 128) or 64
+// (K = 256) beyond.
+int slice_width(int64_t K, int64_t N) {
+  if (K == 256) return N % 64 == 0 ? 64 : 0;
+  if (N <= 128) return (N % 32 == 0) ? static_cast<int>(N) : 0;
+  return N % 128 == 0 ? 128 : 0;
+}
+
 template <int KT>
-int launch_n(const RowsArgs& a, int64_t N, hipStream_t st) {
-  switch (N) {
-    case 32: return launch<KT, 1>(a, st);
-    case 64: return launch<KT, 2>(a, st);
-    case 96: return launch<KT, 3>(a, st);
-    default: return launch<KT, 4>(a, st);
+int launch_n(RowsArgs& a, int64_t K, int64_t N, hipStream_t st) {
+  const int w = slice_width(K, N);
+  a.n_total = static_cast<int>(N);
+  a.slices = static_cast<int>(N / w);
+  if constexpr (KT > 8) {
+    return launch<KT, 2>(a, st);
+  } else {
+    switch (w) {
+      case 32: return launch<KT, 1>(a, st);
+      case 64: return launch<KT, 2>(a, st);
+      case 96: return launch<KT, 3>(a, st);
+      default: return launch<KT, 4>(a, st);
+    }
   }
 }
 
@@ -228,14 +267,16 @@ int launch_n(const RowsArgs& a, int64_t N, hipStream_t st) {
 extern "C" {
 
 int spmi_gemm_rows_supported(int64_t K, int64_t N) {
-  return (K == 32 || K == 64 || K == 128) && (N == 32 || N == 64 || N == 96 || N == 128);
+  if (!(K == 32 || K == 64 || K == 128 || K == 256) || N < 32 || N > 4096) return 0;
+  return slice_width(K, N) != 0;
 }
 
 int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void* w_planes, int64_t N,
                    const float* bias, const float* row_scale, int act, float slope, float* out,
                    int64_t ldo, void* stream) {
   SPMI_REQUIRE(spmi_gemm_rows_supported(K, N), SPMI_ERR_UNSUPPORTED,
-               "spmi_gemm_rows: K must be 32, 64 or 128 and N 32, 64, 96 or 128 (K=%lld N=%lld)",
+               "spmi_gemm_rows: K must be 32, 64, 128 (N = 32..128 in steps of 32, or a multiple of 128) "
+               "or 256 (N a multiple of 64) (K=%lld N=%lld)",
                (long long)K, (long long)N);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: bad M=%lld",
                (long long)M);
@@ -252,9 +293,10 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
   a.x = x; a.ldx = ldx; a.M = M; a.wp = static_cast<const uint4*>(w_planes); a.bias = bias; a.row_scale = row_scale;
   a.act = act; a.slope = slope; a.out = out; a.ldo = ldo;
   hipStream_t st = spmi::as_stream(stream);
-  if (K == 32) return launch_n<2>(a, N, st);
-  if (K == 64) return launch_n<4>(a, N, st);
-  return launch_n<8>(a, N, st);
+  if (K == 32) return launch_n<2>(a, K, N, st);
+  if (K == 64) return launch_n<4>(a, K, N, st);
+  if (K == 128) return launch_n<8>(a, K, N, st);
+  return launch_n<16>(a, K, N, st);
 }
 
 }  // extern "C"

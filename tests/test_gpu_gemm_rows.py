@@ -36,6 +36,27 @@ def test_all_shapes(dev, k, n):
         assert float((got.double().cpu() - want).abs().max()) < 2e-6 * scale, (m, k, n)
 
 
+@pytest.mark.parametrize("k,n", [(256, 512), (256, 64), (256, 192), (128, 256), (64, 512), (128, 384)])
+def test_wide_outputs_in_column_slices(dev, k, n):
+    """N > 128 and K = 256 (the 256 -> 512 projection of the wide-feature workload): column
+    slices computed by different workgroups, with bias, activation and row scale per slice."""
+    assert nv.lib().spmi_gemm_rows_supported(k, n)
+    gen = torch.Generator().manual_seed(k + n)
+    for m in (1, 33, 5000 + 13):
+        x = (torch.randn(m, k, generator=gen) * 2).to(dev)
+        w = (torch.randn(n, k, generator=gen) * 0.1).to(dev)
+        b = torch.randn(n, generator=gen).to(dev)
+        rs = (torch.rand(m, generator=gen) + 0.5).to(dev)
+        got = ops.gemm_rows(x, w, b, "leaky_relu", 0.01, rs)
+        want = _ref(x, w, b, "leaky_relu") * rs.double().cpu()[:, None]
+        scale = float(want.abs().max())
+        assert got.shape == (m, n)
+        assert float((got.double().cpu() - want).abs().max()) < 2e-6 * scale, (m, k, n)
+    assert not nv.lib().spmi_gemm_rows_supported(256, 96)
+    assert not nv.lib().spmi_gemm_rows_supported(128, 160)
+    assert not nv.lib().spmi_gemm_rows_supported(512, 512)
+
+
 def test_closer_to_float64_than_the_library(dev):
     gen = torch.Generator().manual_seed(5)
     x = (torch.randn(200_000, 128, generator=gen) * 2).to(dev)
@@ -111,7 +132,7 @@ def test_rows_of_any_magnitude_and_bad_shapes(dev):
     keep[200] = keep[201] = False
     assert torch.isfinite(out[keep.to(dev)]).all()
     assert not nv.lib().spmi_gemm_rows_supported(48, 32)
-    assert not nv.lib().spmi_gemm_rows_supported(128, 256)
+    assert not nv.lib().spmi_gemm_rows_supported(128, 200)
     with pytest.raises(nv.SpmiError):
         nv.check(nv.lib().spmi_gemm_rows(nv.ptr(x), 32, 4096, 48, nv.ptr(w), 32, None, None, 0, 0.0,
                                          nv.ptr(out), 32, nv.stream()), "spmi_gemm_rows")
