@@ -22,7 +22,8 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
-from spiral_amd.ops import WeightCacheHooks, gcn_aggregate, graphconv_inference, rows_times_weight
+from spiral_amd.ops import (WeightCacheHooks, gcn_aggregate, graphconv_inference, project_rows_inference,
+                            rows_times_weight)
 
 
 def _classify_activation(act) -> Tuple[Optional[str], float, Optional[Callable]]:
@@ -105,7 +106,12 @@ class GraphConv(WeightCacheHooks, nn.Module):
         else:
             rst = gcn_aggregate(graph, feat, self._norm, None, edge_weight, None)
             bias = None if self.bias is None else self.bias.to(rst.dtype)
-            if weight is not None:
+            fused = None
+            if weight is not None and not tracked and rst.dtype == torch.float32:
+                fused = project_rows_inference(rst, weight, bias, code, slope)
+            if fused is not None:
+                rst, code = fused, None  # bias and activation rode in the projection's epilogue
+            elif weight is not None:
                 rst = rows_times_weight(rst, weight, bias)
             elif bias is not None:
                 rst = rst + bias

@@ -199,6 +199,17 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
                      None if bias is None else bias.detach(), act, slope)
 
 
+def project_rows_inference(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
+                           act: Optional[str], slope: float) -> Optional[torch.Tensor]:
+    """act(x @ w + bias) for w [K, N] in one pass over the rows (projection, bias and
+    activation in the epilogue of spmi_gemm_rows), or None when the shape is not covered.
+    No autograd: for layers that aggregate first and multiply afterwards."""
+    if act not in (None, "none", "relu", "leaky_relu") or not _gemm_rows_ok(x, w.shape[0], w.shape[1]):
+        return None
+    return gemm_rows(x, w.detach().t(), bias, act, slope,
+                     planes=weight_planes(w, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
+
+
 def _mm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x @ w (+ bias), w [K, N], no autograd."""
     if _gemm_rows_ok(x, w.shape[0], w.shape[1]):

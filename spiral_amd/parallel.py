@@ -479,12 +479,10 @@ def _finish(conv, rst: torch.Tensor, code, slope, unfused) -> torch.Tensor:
     import torch.nn.functional as F
 
     weight = conv.weight
-    if (weight is not None and not _tracked(conv, rst) and code in (None, "relu", "leaky_relu")
-            and ops._gemm_rows_ok(rst, weight.shape[0], weight.shape[1])):
-        # projection, bias and activation in one pass over the rows
-        rst = ops.gemm_rows(rst, weight.detach().t(), conv.bias, code, slope,
-                            planes=ops.weight_planes(weight, "f16x3", True, ops.F16X3_GEMM_ROWS_LIMIT))
-        return rst if unfused is None else unfused(rst)
+    if weight is not None and not _tracked(conv, rst):
+        fused = ops.project_rows_inference(rst, weight, conv.bias, code, slope)
+        if fused is not None:  # projection, bias and activation in one pass over the rows
+            return fused if unfused is None else unfused(fused)
     if weight is not None:
         rst = ops.rows_times_weight(rst, weight, conv.bias)
     elif conv.bias is not None:
