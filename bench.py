@@ -668,7 +668,7 @@ def main():
             "stages": stages,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, world, widths),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None if train else measured_traffic(args.workload, world, widths),
                 "kernel": "; ".join(aggregation_kernel_name(fw, kind == "evolve_bf16") for fw in widths),
                 "feature_widths": widths,
                 "avg_launch_ms": spmm_avg_ms, "launches": len(spmm_ms),

@@ -125,6 +125,18 @@ int spmi_norm_from_indptr(const int32_t* indptr /*device [N+1]*/, int64_t N, int
 int spmi_norm_from_degree(const int64_t* deg /*device [N]*/, int64_t N, int mode,
                           float* norm /*device [N]*/, void* stream);
 
+/* The normaliser of the side of GraphConv whose CSR is not built, straight from a column of
+ * 32-bit node ids that the library itself produced and range-checked (the `indices` of the
+ * other side's CSR): norm[v] = f(number of occurrences of v in ids), f as in
+ * spmi_norm_from_indptr; deg (nullable, int64 [N]) receives the counts.  Same reference lines
+ * as spmi_degree + spmi_norm_from_degree (the out_degrees() / clamp / pow of dgl
+ * GraphConv.forward), half the bytes of a second pass over the caller's int64 ids and one
+ * launch less.  Workspace: spmi_degree_workspace_bytes(E, N).  ids outside [0, N) are not
+ * detected here (no access leaves the buffers; the counts are then meaningless). */
+int spmi_norm_from_ids32(const int32_t* ids /*device [E]*/, int64_t E, int64_t N, int mode,
+                         float* norm /*device [N]*/, int64_t* deg /*nullable, device [N]*/, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Load-balance plan for the aggregation: rows whose degree exceeds
  * `heavy_thresh` are listed and cut into chunks of `chunk` nonzeros that

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "spmi_csr_prefix_degree": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "spmi_norm_from_indptr": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "spmi_norm_from_degree": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "spmi_norm_from_ids32": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "spmi_spmm_plan": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "spmi_gcn_spmm": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp,
                               c_vp, c_vp, c_int, c_f32, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32,

@@ -307,7 +307,7 @@ constexpr int kCountThreads = 1024;
 
 __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ totals, int64_t N,
-    int64_t* __restrict__ deg) {
+    int64_t* __restrict__ deg, float* __restrict__ norm, int mode) {
   __shared__ uint32_t s_hist[1 << kCountLow];
   __shared__ uint32_t s_start;
   const int b = blockIdx.x;
@@ -322,8 +322,14 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
     atomicAdd(&s_hist[keys[start + i] & ((1u << kCountLow) - 1u)], 1u);
   __syncthreads();
   const int64_t node0 = static_cast<int64_t>(b) << kCountLow;
-  for (int j = tid; j < (1 << kCountLow); j += kCountThreads)
-    if (node0 + j < N) deg[node0 + j] = s_hist[j];
+  for (int j = tid; j < (1 << kCountLow); j += kCountThreads) {
+    if (node0 + j >= N) continue;
+    if (deg) deg[node0 + j] = s_hist[j];
+    if (norm) {  // the normaliser of this degree, in the same pass
+      const float d = fmaxf(static_cast<float>(s_hist[j]), 1.0f);
+      norm[node0 + j] = (mode == SPMI_NORM_RSQRT) ? (1.0f / sqrtf(d)) : (1.0f / d);
+    }
+  }
 }
 
 __global__ void norm_from_degree_kernel(const int64_t* __restrict__ deg, int64_t N, int mode,
@@ -597,7 +603,7 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
         ids, nullptr, nullptr, nullptr, b.keys[0], nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow,
         bits, b.hist, b.totals, sh.n_tiles, status);
     SPMI_CHECK_LAUNCH("radix_scatter(degree)");
-    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg);
+    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, nullptr, 0);
     SPMI_CHECK_LAUNCH("bucket_count");
     return SPMI_OK;
   }
@@ -607,6 +613,81 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
   SPMI_CHECK_LAUNCH("csr_finalize(degree)");
   indptr_to_degree_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, deg);
   SPMI_CHECK_LAUNCH("indptr_to_degree");
+  return SPMI_OK;
+}
+
+int spmi_norm_from_ids32(const int32_t* ids, int64_t E, int64_t N, int mode, float* norm,
+                         int64_t* deg, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_sizes(E, N, "spmi_norm_from_ids32")) return rc;
+  SPMI_REQUIRE(norm, SPMI_ERR_INVALID_ARG, "spmi_norm_from_ids32: null norm");
+  SPMI_REQUIRE(mode == SPMI_NORM_RSQRT || mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
+               "spmi_norm_from_ids32: bad mode %d", mode);
+  SPMI_REQUIRE(E == 0 || (ids && ws), SPMI_ERR_INVALID_ARG, "spmi_norm_from_ids32: null pointer argument");
+  SPMI_REQUIRE(ws_bytes >= spmi_degree_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
+               "spmi_norm_from_ids32: workspace %zu < required %zu", ws_bytes,
+               spmi_degree_workspace_bytes(E, N));
+  hipStream_t st = spmi::as_stream(stream);
+  const SortShape sh = sort_shape(E, N);
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  const size_t np = spmi::align_up(sizeof(int32_t) * (size_t)(N + 1), 256);
+  char* p = static_cast<char*>(ws);
+  SortBuffers b{};
+  b.keys[0] = reinterpret_cast<uint32_t*>(p);
+  b.keys[1] = reinterpret_cast<uint32_t*>(p + e4);
+  int32_t* indptr = reinterpret_cast<int32_t*>(p + 2 * e4);
+  b.hist = reinterpret_cast<uint32_t*>(p + 2 * e4 + np);
+  b.totals = reinterpret_cast<uint32_t*>(
+      p + 2 * e4 + np + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(ids);
+  const dim3 grid(sh.n_tiles), block(kThreads);
+  int32_t* no_status = nullptr;  // 32-bit keys are never range-checked (checked_key passes them through)
+  if (E > 0 && N <= (int64_t{1} << (kCountLow + 8))) {
+    const int n_buckets = static_cast<int>((N + (1 << kCountLow) - 1) >> kCountLow);
+    int bits = 1;
+    while ((1 << bits) < n_buckets) ++bits;
+    radix_hist_kernel<uint32_t><<<grid, block, 0, st>>>(keys, E, (uint32_t)N, kCountLow, bits, b.hist,
+                                                        sh.n_tiles, no_status);
+    SPMI_CHECK_LAUNCH("radix_hist(ids32)");
+    radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
+    SPMI_CHECK_LAUNCH("radix_scan(ids32)");
+    radix_scatter_kernel<uint32_t, false, 0><<<grid, block, 0, st>>>(
+        keys, nullptr, nullptr, nullptr, b.keys[0], nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow,
+        bits, b.hist, b.totals, sh.n_tiles, no_status);
+    SPMI_CHECK_LAUNCH("radix_scatter(ids32)");
+    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, norm, mode);
+    SPMI_CHECK_LAUNCH("bucket_count(ids32)");
+    return SPMI_OK;
+  }
+  if (E == 0) {
+    SPMI_CHECK_HIP(hipMemsetAsync(indptr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
+  } else {
+    // keys-only sort of the 32-bit ids, then run boundaries
+    int shift = 0;
+    for (int q = 0; q < sh.passes; ++q) {
+      const int bits = sh.pass_bits[q];
+      const int out = (sh.passes - 1 - q) & 1;
+      const uint32_t* in = q == 0 ? keys : b.keys[out ^ 1];
+      radix_hist_kernel<uint32_t><<<grid, block, 0, st>>>(in, E, (uint32_t)N, shift, bits, b.hist,
+                                                          sh.n_tiles, no_status);
+      SPMI_CHECK_LAUNCH("radix_hist(ids32)");
+      radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
+      SPMI_CHECK_LAUNCH("radix_scan(ids32)");
+      radix_scatter_kernel<uint32_t, false, 0><<<grid, block, 0, st>>>(
+          in, nullptr, nullptr, nullptr, b.keys[out], nullptr, nullptr, E, (uint32_t)N, 1u, shift, bits,
+          b.hist, b.totals, sh.n_tiles, no_status);
+      SPMI_CHECK_LAUNCH("radix_scatter(ids32)");
+      shift += bits;
+    }
+    const int fgrid = static_cast<int>((E + kThreads - 1) / kThreads);
+    csr_finalize_kernel<<<fgrid, kThreads, 0, st>>>(b.keys[0], E, N, indptr);
+    SPMI_CHECK_LAUNCH("csr_finalize(ids32)");
+  }
+  norm_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, mode, norm);
+  SPMI_CHECK_LAUNCH("norm(ids32)");
+  if (deg) {
+    indptr_to_degree_kernel<<<(int)((N + 255) / 256), 256, 0, st>>>(indptr, N, deg);
+    SPMI_CHECK_LAUNCH("indptr_to_degree(ids32)");
+  }
   return SPMI_OK;
 }
 

@@ -227,6 +227,22 @@ def degree(ids: torch.Tensor, n: int, validated: bool = False) -> torch.Tensor:
     return out
 
 
+def norm_from_ids32(ids: torch.Tensor, n: int, mode: int) -> torch.Tensor:
+    """clamp(count of v in ids, 1)^-0.5 (mode 0) or its reciprocal (mode 1) for v in [0, n), from
+    an int32 id column the library wrote itself (a CSR's `indices`)."""
+    nv.require_cuda(ids)
+    if ids.dtype != torch.int32 or not ids.is_contiguous():
+        raise nv.SpmiError("norm_from_ids32 expects a contiguous int32 id column")
+    lib = nv.lib()
+    with torch.cuda.device(ids.device):
+        out = torch.empty(n, dtype=torch.float32, device=ids.device)
+        ws_bytes = lib.spmi_degree_workspace_bytes(ids.numel(), n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=ids.device)
+        nv.check(lib.spmi_norm_from_ids32(nv.ptr(ids), ids.numel(), n, mode, nv.ptr(out), None, nv.ptr(ws),
+                                          ws_bytes, nv.stream()), "spmi_norm_from_ids32")
+    return out
+
+
 def norm_from_degree(deg: torch.Tensor, mode: int) -> torch.Tensor:
     """clamp(deg, 1)^-0.5 (mode 0) or 1/clamp(deg, 1) (mode 1) as fp32, one launch."""
     nv.require_cuda(deg)
@@ -509,9 +525,13 @@ class SnapshotGraph(NormalisedAdjacency):
                 self._norms[key] = self.csr_t(wait=False).norm(mode)
             else:
                 # The by-destination build range-checks both id arrays, and the aggregation
-                # that uses this normaliser collects its verdict.
-                self.csr(wait=False)
-                self._norms[key] = norm_from_degree(self.out_degrees(), mode)
+                # that uses this normaliser collects its verdict.  Its source column (int32,
+                # ids clamped into range) is counted instead of a second pass over the int64 ids.
+                csr = self.csr(wait=False)
+                if self._out_deg is None and self._table is None:
+                    self._norms[key] = norm_from_ids32(csr.indices, self._n, mode)
+                else:
+                    self._norms[key] = norm_from_degree(self.out_degrees(), mode)
         return self._norms[key]
 
 

@@ -141,3 +141,30 @@ def test_norm_matches_oracle(dev):
             with torch.no_grad():
                 got = g.norm(side, mode).cpu().numpy()
             np.testing.assert_allclose(got, orc.norm_from_indptr(ip, name), rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("n,e", [(1000, 20_000), (1 << 20, 300_000), ((1 << 20) + 5, 200_000), (3_000_000, 400_000), (7, 0)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_normaliser_from_a_32_bit_id_column(dev, n, e, mode):
+    """spmi_norm_from_ids32 (the source normaliser counted from the by-destination CSR's own
+    int32 column) equals clamp(bincount, 1)^-1/2 resp. its reciprocal bit for bit with the
+    kernels that go through int64 degrees, and the counts equal the oracle's degrees."""
+    from spiral_amd import _native as nv
+
+    rng = np.random.default_rng(n + e)
+    ids = rng.integers(0, n, e).astype(np.int32)
+    if e:
+        ids[: e // 3] = ids[0]                                   # a hub
+    t = torch.from_numpy(ids).to(dev)
+    got = G.norm_from_ids32(t, n, mode)
+    want_deg = orc.degree(ids.astype(np.int64), n)
+    want = G.norm_from_degree(torch.from_numpy(want_deg).to(dev), mode)
+    assert torch.equal(got, want)
+    lib = nv.lib()
+    deg = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    out = torch.empty(n, device=dev)
+    nbytes = lib.spmi_degree_workspace_bytes(e, n)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    nv.check(lib.spmi_norm_from_ids32(nv.ptr(t), e, n, mode, nv.ptr(out), nv.ptr(deg), nv.ptr(ws), nbytes,
+                                      nv.stream()), "spmi_norm_from_ids32")
+    assert np.array_equal(deg.cpu().numpy(), want_deg) and torch.equal(out, want)
