@@ -84,11 +84,19 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const KeyT* __rest
   for (int d = threadIdx.x; d < ndig; d += kThreads) s_hist[d] = 0;
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
-#pragma unroll 4
+  // all loads of the thread first (positions past the end read the last key, which is then
+  // not counted), so that they are in flight together
+  KeyT raw[kKeysPerThread];
+#pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) {
-    int64_t i = base + j * kThreads + threadIdx.x;
+    const int64_t i = base + j * kThreads + threadIdx.x;
+    raw[j] = keys[i < E ? i : E - 1];
+  }
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = base + j * kThreads + threadIdx.x;
     if (i < E) {
-      uint32_t k = checked_key(keys[i], N, status);
+      const uint32_t k = checked_key(raw[j], N, status);
       atomicAdd(&s_hist[(k >> shift) & mask], 1u);
     }
   }
