@@ -308,6 +308,167 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_partial_x3_kernel(
     }
 }
 
+// The piece kernel for outputs made of whole 128 x 128 blocks (the gate and layer weights of
+// the path: 128 x 128, 384 x 128).  A wave owns one such block and a chunk of K.
+//  * Which matrix column a lane's operand vector stands for is the kernel's choice as long as
+//    the output is stored by the same rule, so a lane reads FOUR neighbouring columns of eight
+//    rows (eight 16-byte loads per operand and K-step, each instruction two 512-byte row
+//    segments) and the four 32-column tiles of the instruction grid are the columns = 0, 1, 2,
+//    3 (mod 4): tile j of lane lr is column 4 lr + j.  Against the 32 x 32-tile kernel above:
+//    a quarter of the load instructions, every split piece feeds four products instead of two
+//    (the split is what bounds the small tiles), and an operand is re-read by M / 128 (N / 128)
+//    waves instead of M / 64 (N / 64).
+//  * A K-step has three phases: every operand value is split (all vector work; the loaded
+//    registers are dead afterwards), the loads of the next step are issued into them, and the
+//    96 matrix instructions run while those loads are in flight.  No loaded value is used
+//    later than the split of its own step, so that nothing the compiler could turn into a
+//    copy (which would wait for the load) crosses the bottom of the loop.
+//  * The 256 accumulators take the whole accumulation register file: one wave per SIMD.
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
+    int M, int N, int64_t k_chunk, int n_chunks, float* __restrict__ partial,
+    float* __restrict__ sum_a_partial, float* __restrict__ sum_b_partial) {
+  const int lane = threadIdx.x & 63;
+  const int m_blocks = M / 128, blocks = m_blocks * (N / 128);
+  // wave-uniform by construction; said so, row bases stay in scalar registers
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWaves + (threadIdx.x >> 6));
+  const int chunk = w / blocks, blk = w % blocks;
+  if (chunk >= n_chunks) return;
+  const int m0 = (blk % m_blocks) * 128, n0 = (blk / m_blocks) * 128;
+  const int64_t k_begin = static_cast<int64_t>(chunk) * k_chunk;
+  const int64_t k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
+  const int lr = lane & 31, lh = lane >> 5;
+  const uint32_t a_off = static_cast<uint32_t>(lh * 8 * lda + m0 + 4 * lr);
+  const uint32_t b_off = static_cast<uint32_t>(lh * 8 * ldb + n0 + 4 * lr);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.0f;
+  const bool want_sa = sum_a_partial != nullptr && n0 == 0;
+  const bool want_sb = sum_b_partial != nullptr && m0 == 0;
+  f32x4 sa = {}, sb = {};
+
+  // Rows past the chunk's end are read from its last row (valid memory) and zeroed.
+  auto load = [&](auto full_tag, int64_t k, f32x4 (&av)[8], f32x4 (&bv)[8]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int64_t row = k + u;  // this lane reads row + 8 lh (the lane half is in the offsets)
+      if constexpr (!FULL) {
+        const int64_t last = k_end - 1 - 8 * lh;
+        row = row > last ? last : row;
+      }
+      av[u] = *reinterpret_cast<const f32x4*>(A + row * lda + a_off);
+      bv[u] = *reinterpret_cast<const f32x4*>(B + row * ldb + b_off);
+    }
+  };
+  bf16x8 ah[4], am[4], al[4], bh[4], bm[4], bl[4];
+  auto split_all = [&](auto full_tag, int64_t k, f32x4 (&av)[8], f32x4 (&bv)[8]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    if constexpr (!FULL) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k + 8 * lh + u >= k_end) {
+          av[u] = f32x4{};
+          bv[u] = f32x4{};
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sa += av[u];
+      sb += bv[u];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[8], w8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = av[u][j];
+        w8[u] = bv[u][j];
+      }
+      split3x8(v, ah[j], am[j], al[j]);
+      split3x8(w8, bh[j], bm[j], bl[j]);
+    }
+  };
+  auto multiply = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {  // smallest terms first
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bm[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bh[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bm[t], acc[s][t], 0, 0, 0);
+        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[t], acc[s][t], 0, 0, 0);
+      }
+  };
+
+  // k_chunk is a multiple of 16, so only the last chunk of K can end in a partial step
+  f32x4 a[8], b[8], a2[8], b2[8];
+  const int64_t n_full = (k_end - k_begin) / 16;
+  int64_t k = k_begin;
+  if (n_full > 0) load(std::true_type{}, k, a, b);
+  int64_t i = 0;
+  for (; i + 2 <= n_full; i += 2, k += 32) {
+    // two steps per trip, two sets of load registers: a step's loads are issued a whole step
+    // ahead.  No branch around the loads (the wait counts stay exact): the last trip re-reads
+    // its own rows.
+    load(std::true_type{}, k + 16, a2, b2);
+    __builtin_amdgcn_sched_barrier(0);
+    split_all(std::true_type{}, k, a, b);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+    load(std::true_type{}, i + 2 < n_full ? k + 32 : k, a, b);
+    __builtin_amdgcn_sched_barrier(0);
+    split_all(std::true_type{}, k + 16, a2, b2);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (i < n_full) {
+    split_all(std::true_type{}, k, a, b);
+    multiply();
+    k += 16;
+  }
+  if (k < k_end) {
+    load(std::false_type{}, k, a, b);
+    split_all(std::false_type{}, k, a, b);
+    multiply();
+  }
+
+  if (want_sa) {  // rows k + 0..7 and k + 8..15 of every step sit in the two lane halves
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = sa[c] + __shfl_xor(sa[c], 32);
+    if (lh == 0) *reinterpret_cast<f32x4*>(sum_a_partial + static_cast<size_t>(chunk) * M + m0 + 4 * lr) = v;
+  }
+  if (want_sb) {
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = sb[c] + __shfl_xor(sb[c], 32);
+    if (lh == 0) *reinterpret_cast<f32x4*>(sum_b_partial + static_cast<size_t>(chunk) * N + n0 + 4 * lr) = v;
+  }
+  // element e of lane l in tile (s, t): row index (e&3) + 8 (e>>2) + 4 lh and column index lr
+  // of the instruction grid, i.e. C[m0 + 4 * row index + s][n0 + 4 lr + t]
+  float* out = partial + static_cast<size_t>(chunk) * M * N;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * lh) + s;
+      const f32x4 v = {acc[s][0][e], acc[s][1][e], acc[s][2][e], acc[s][3][e]};
+      *reinterpret_cast<f32x4*>(out + static_cast<size_t>(m) * N + n0 + 4 * lr) = v;
+    }
+}
+
 // C = (accumulate ? C : 0) + sum over chunks.  L lanes share one output element: lane c of
 // the group adds chunks c, c+L, ... and the group is folded by a shuffle tree, so the order
 // of additions is fixed by the shape alone.  Inside a wave the 64/L elements are the fast
@@ -366,6 +527,26 @@ Shape plan(int64_t M, int64_t N, int64_t K, bool pieces) {
   return s;
 }
 
+// The 128 x 128-block kernel: one wave per SIMD over the whole chip, one block and one chunk
+// of K per wave.
+bool wide_shape(int64_t M, int64_t N) { return M % 128 == 0 && N % 128 == 0 && M * N <= 512 * 512; }
+
+Shape plan_wide(int64_t M, int64_t N, int64_t K) {
+  Shape s{};
+  s.mt = s.nt = 4;
+  s.m_strips = static_cast<int>(M / 128);
+  s.n_tiles = static_cast<int>(N / 128);
+  const int64_t blocks = s.m_strips * s.n_tiles;
+  // one wave per SIMD over the whole chip
+  int64_t chunks = 1024 / blocks;
+  const int64_t max_chunks = (K + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  s.k_chunk = ((K + chunks - 1) / chunks + 15) / 16 * 16;
+  s.n_chunks = static_cast<int>((K + s.k_chunk - 1) / s.k_chunk);
+  return s;
+}
+
 int check_gemm_tn(int64_t M, int64_t N, int64_t K) {
   SPMI_REQUIRE(M >= 1 && N >= 1 && K >= 1 && M <= 4096 && N <= 4096 && K < (int64_t{1} << 40),
                SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: bad sizes M=%lld N=%lld K=%lld (M, N <= 4096)",
@@ -381,7 +562,11 @@ size_t spmi_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || K < 1 || M > 4096 || N > 4096) return 0;
   // the two kernels cut K differently: room for the finer cut
   const Shape s0 = plan(M, N, K, false), s1 = plan(M, N, K, true);
-  const int chunks = s0.n_chunks > s1.n_chunks ? s0.n_chunks : s1.n_chunks;
+  int chunks = s0.n_chunks > s1.n_chunks ? s0.n_chunks : s1.n_chunks;
+  if (wide_shape(M, N)) {
+    const int cw = plan_wide(M, N, K).n_chunks;
+    chunks = cw > chunks ? cw : chunks;
+  }
   return sizeof(float) * static_cast<size_t>(chunks) * (M * N + M + N);
 }
 
@@ -405,7 +590,9 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
                "spmi_gemm_tn: workspace %zu < required %zu", ws_bytes,
                spmi_gemm_tn_workspace_bytes(M, N, K));
   const bool pieces = fp32_instruction == 0;
-  const Shape s = plan(M, N, K, pieces);
+  const bool wide = pieces && wide_shape(M, N) && lda % 4 == 0 && ldb % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u) == 0;
+  const Shape s = wide ? plan_wide(M, N, K) : plan(M, N, K, pieces);
   SPMI_REQUIRE(lda < (int64_t{1} << 27) && ldb < (int64_t{1} << 27), SPMI_ERR_UNSUPPORTED,
                "spmi_gemm_tn: leading dimension too large");
   hipStream_t st = spmi::as_stream(stream);
@@ -420,7 +607,11 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
   gemm_tn_partial_x3_kernel<MT, NT><<<grid, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N, \
                                                                s.k_chunk, partial, s.m_strips,   \
                                                                s.n_tiles, pa, pb)
-  if (pieces) {
+  if (wide) {
+    const unsigned wgs = static_cast<unsigned>((s.m_strips * s.n_tiles * s.n_chunks + kWaves - 1) / kWaves);
+    gemm_tn_partial_x3_wide_kernel<<<wgs, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N, s.k_chunk,
+                                                             s.n_chunks, partial, pa, pb);
+  } else if (pieces) {
     if (s.mt == 2 && s.nt == 2) SPMI_GEMM_TN_X3(2, 2);
     else if (s.mt == 2) SPMI_GEMM_TN_X3(2, 1);
     else if (s.nt == 2) SPMI_GEMM_TN_X3(1, 2);
