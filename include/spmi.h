@@ -266,6 +266,13 @@ int spmi_gru_gate_fwd(const float* gi /*[M,3H]*/, const float* gh /*[M,3H]*/,
 int spmi_gru_gate_bwd(const float* gh_out /*[M,H] grad of h_out*/, const float* saved /*[M,5H]*/,
                       int64_t M, int64_t H, float* g_gi /*[M,3H]*/, float* g_gh /*[M,3H]*/,
                       float* g_h /*nullable [M,H]: direct path gh_out*z*/, void* stream);
+/* The gate gradients of spmi_gru_gate_bwd as one matrix g4 [M,4H] = [d a_n | d a_r | d a_z |
+ * d a_n * r]: columns 0..3H are g_gi with the gates in the order n, r, z, columns H..4H are
+ * g_gh (r, z, n); a third less to write and to read back than the two matrices.  Replaces
+ * the same autograd step of torch.nn.GRU (implicitTimeModels.py:185-187) as spmi_gru_gate_bwd. */
+int spmi_gru_gate_bwd_packed(const float* gh_out /*[M,H]*/, const float* saved /*[M,5H]*/, int64_t M,
+                             int64_t H, float* g4 /*[M,4H]*/, float* g_h /*nullable [M,H]*/,
+                             void* stream);
 int spmi_lstm_gate_fwd(const float* gi /*[M,4H]*/, const float* gh /*[M,4H]*/,
                        const float* b_ih, const float* b_hh, float* h_mem, float* c_mem,
                        const int64_t* ids, int64_t M, int64_t H, float* h_out, float* c_out,
@@ -360,7 +367,7 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
  * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites
  * staticGraphEncoder.py:113,116; likewise SGConv / SAGEConv's fc layers) and the Linear
  * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} with
- * N in {32, 64, 96, 128} or any multiple of 128, and K = 256 with N a multiple of 64 (wide
+ * N in {32, 64, 96, 128} or any multiple of 128, and K = 256 or 384 with N a multiple of 64 (wide
  * outputs are computed in column slices by workgroups that share an XCD's L2).  fp32 results from the fp16 matrix cores with the three-plane
  * operand format of spmi_cell_f16x3_fwd (same accuracy).  The rows of x may hold any finite
  * fp32 value (each row is scaled by a power of two before it is split and its results by the

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "spmi_gru_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
                                   c_vp, c_vp]),
     "spmi_gru_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "spmi_gru_gate_bwd_packed": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "spmi_lstm_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                    c_vp, c_int, c_vp, c_vp]),
     "spmi_lstm_gate_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),

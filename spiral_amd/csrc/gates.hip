@@ -152,6 +152,42 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(const float* __restri
   if (g_h) st<VEC>(g_h + e.m * H + e.j, dh);
 }
 
+// The same gate gradients as ONE matrix [M, 4H] = [d a_n | d a_r | d a_z | d a_n * r]: its
+// columns 0..3H are the gradient of the input-side pre-activations (gate order n, r, z), its
+// columns H..4H that of the state side (gate order r, z, n), so that the layer's backward
+// reads what gru_bwd_kernel writes as two [M, 3H] matrices from two thirds of the bytes.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void gru_bwd_packed_kernel(const float* __restrict__ g_out,
+                                                                  const float* __restrict__ saved,
+                                                                  int64_t M, int H,
+                                                                  float* __restrict__ g4,
+                                                                  float* __restrict__ g_h) {
+  Elem e;
+  if (!decode<VEC>(M, H, &e)) return;
+  const float* s = saved + e.m * 5 * H + e.j;
+  const Pack<VEC> g = ld<VEC>(g_out + e.m * H + e.j);
+  const Pack<VEC> r = ld<VEC>(s), z = ld<VEC>(s + H), n = ld<VEC>(s + 2 * H),
+                  hn = ld<VEC>(s + 3 * H), h = ld<VEC>(s + 4 * H);
+  Pack<VEC> dar, daz, dan, danr, dh;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {  // the same expressions, in the same order, as gru_bwd_kernel
+    const float dn = g.v[i] * (1.0f - z.v[i]);
+    const float dz = g.v[i] * (h.v[i] - n.v[i]);
+    dan.v[i] = dn * (1.0f - n.v[i] * n.v[i]);
+    daz.v[i] = dz * z.v[i] * (1.0f - z.v[i]);
+    const float dr = dan.v[i] * hn.v[i];
+    dar.v[i] = dr * r.v[i] * (1.0f - r.v[i]);
+    danr.v[i] = dan.v[i] * r.v[i];
+    dh.v[i] = g.v[i] * z.v[i];
+  }
+  const int64_t g0 = e.m * 4 * H + e.j;
+  st<VEC>(g4 + g0, dan);
+  st<VEC>(g4 + g0 + H, dar);
+  st<VEC>(g4 + g0 + 2 * H, daz);
+  st<VEC>(g4 + g0 + 3 * H, danr);
+  if (g_h) st<VEC>(g_h + e.m * H + e.j, dh);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void lstm_fwd_kernel(
     const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ b_ih,
@@ -326,6 +362,17 @@ int spmi_gru_gate_bwd(const float* gh_out, const float* saved, int64_t M, int64_
   const bool v4 = (H % 4 == 0) && all_aligned16({gh_out, saved, g_gi, g_gh, g_h});
   SPMI_LAUNCH_VEC(gru_bwd_kernel, v4, M, H, spmi::as_stream(stream), gh_out, saved, M,
                   static_cast<int>(H), g_gi, g_gh, g_h);
+  return SPMI_OK;
+}
+
+int spmi_gru_gate_bwd_packed(const float* gh_out, const float* saved, int64_t M, int64_t H, float* g4,
+                             float* g_h, void* stream) {
+  if (int rc = check_mh(M, H, "spmi_gru_gate_bwd_packed")) return rc;
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(gh_out && saved && g4, SPMI_ERR_INVALID_ARG, "spmi_gru_gate_bwd_packed: null pointer");
+  const bool v4 = (H % 4 == 0) && all_aligned16({gh_out, saved, g4, g_h});
+  SPMI_LAUNCH_VEC(gru_bwd_packed_kernel, v4, M, H, spmi::as_stream(stream), gh_out, saved, M,
+                  static_cast<int>(H), g4, g_h);
   return SPMI_OK;
 }
 

@@ -24,8 +24,8 @@
 //    K-step t of the wave's next tile, so 16 KB per wave (128 KB per CU) are in flight while
 //    the matrix cores work;
 //  * waves are independent after the weight load: no barrier in the loop;
-//  * wide outputs (N > 128) and K = 256 are cut into column slices of 128 (64 for K = 256)
-//    that fit LDS: the workgroups that hold the slices of one row range run on one XCD
+//  * wide outputs (N > 128) and K = 256, 384 are cut into column slices of 128 (64 for
+//    K = 256, 384) that fit LDS: the workgroups that hold the slices of one row range run on one XCD
 //    (blockIdx -> XCD is round-robin) and walk the same tiles, so the rows they all read
 //    come from HBM once and from that XCD's L2 afterwards.
 
@@ -238,9 +238,9 @@ int launch(const RowsArgs& a, hipStream_t st) {
 }
 
 // Columns per workgroup: the whole weight up to 128 columns, slices of 128 (K <= 128) or 64
-// (K = 256) beyond.
+// (K = 256, 384) beyond.
 int slice_width(int64_t K, int64_t N) {
-  if (K == 256) return N % 64 == 0 ? 64 : 0;
+  if (K == 256 || K == 384) return N % 64 == 0 ? 64 : 0;
   if (N <= 128) return (N % 32 == 0) ? static_cast<int>(N) : 0;
   return N % 128 == 0 ? 128 : 0;
 }
@@ -267,7 +267,7 @@ int launch_n(RowsArgs& a, int64_t K, int64_t N, hipStream_t st) {
 extern "C" {
 
 int spmi_gemm_rows_supported(int64_t K, int64_t N) {
-  if (!(K == 32 || K == 64 || K == 128 || K == 256) || N < 32 || N > 4096) return 0;
+  if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 384) || N < 32 || N > 4096) return 0;
   return slice_width(K, N) != 0;
 }
 
@@ -276,7 +276,7 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
                    int64_t ldo, void* stream) {
   SPMI_REQUIRE(spmi_gemm_rows_supported(K, N), SPMI_ERR_UNSUPPORTED,
                "spmi_gemm_rows: K must be 32, 64, 128 (N = 32..128 in steps of 32, or a multiple of 128) "
-               "or 256 (N a multiple of 64) (K=%lld N=%lld)",
+               "or 256, 384 (N a multiple of 64) (K=%lld N=%lld)",
                (long long)K, (long long)N);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: bad M=%lld",
                (long long)M);
@@ -296,7 +296,8 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
   if (K == 32) return launch_n<2>(a, K, N, st);
   if (K == 64) return launch_n<4>(a, K, N, st);
   if (K == 128) return launch_n<8>(a, K, N, st);
-  return launch_n<16>(a, K, N, st);
+  if (K == 256) return launch_n<16>(a, K, N, st);
+  return launch_n<24>(a, K, N, st);
 }
 
 }  // extern "C"

@@ -733,6 +733,11 @@ def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
     return h_out
 
 
+# GRU layers hand their gate gradients to the dense kernels as one [rows, 4H] matrix instead of
+# two [rows, 3H] ones (see GruCell._backward_packed).
+GRU_PACKED_BACKWARD = True
+
+
 class GruCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
@@ -758,10 +763,41 @@ class GruCell(torch.autograd.Function):
         return h_out
 
     @staticmethod
+    def _backward_packed(ctx, g_h):
+        """The backward with the gate gradients as one [M, 4H] matrix [n | r | z | n*r] (one
+        write, read back as two overlapping [M, 3H] views): columns 0..3H are the gradient of
+        x W_ih^T with the gates in the order n, r, z, columns H..4H that of h W_hh^T in torch's
+        order r, z, n.  dX comes from spmi_gemm_rows with the rows of W_ih reordered to match."""
+        xd, w_ih, w_hh, saved = ctx.saved_tensors
+        m, hd = g_h.shape
+        g4 = torch.empty(m, 4 * hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_gru_gate_bwd_packed(nv.ptr(g_h), nv.ptr(saved), m, hd, nv.ptr(g4),
+                                                       None, nv.stream()), "spmi_gru_gate_bwd_packed")
+        g_i, g_hh = g4[:, : 3 * hd], g4[:, hd:]
+        h_old = saved[:, 4 * hd:]
+        nrz = lambda t: torch.cat([t[2 * hd:], t[: 2 * hd]])      # torch's r, z, n -> n, r, z
+        rzn = lambda t: torch.cat([t[hd:], t[:hd]])               # and back
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            w_nrz = nrz(w_ih.detach())                             # [3H, I]
+            g_x = gemm_rows(g_i, w_nrz.t()) if _gemm_rows_ok(g_i, 3 * hd, w_ih.shape[1]) else g_i @ w_nrz
+        need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        need_bhh = ctx.has_bias and ctx.needs_input_grad[4]
+        g_wih, g_bih = _weight_and_bias_grad(g_i, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
+        g_whh, g_bhh = _weight_and_bias_grad(g_hh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
+        if g_wih is not None:
+            g_wih = rzn(g_wih)
+        g_bih = rzn(g_bih) if (g_bih is not None and ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
+
+    @staticmethod
     def backward(ctx, g_h):
         xd, w_ih, w_hh, saved = ctx.saved_tensors
         m, hd = g_h.shape
         g_h = g_h.contiguous()
+        if GRU_PACKED_BACKWARD and hd % 4 == 0:
+            return GruCell._backward_packed(ctx, g_h)
         g_gi = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_h.device)
         g_gh = torch.empty(m, 3 * hd, dtype=torch.float32, device=g_h.device)
         with torch.cuda.device(g_h.device):

@@ -36,10 +36,12 @@ def test_all_shapes(dev, k, n):
         assert float((got.double().cpu() - want).abs().max()) < 2e-6 * scale, (m, k, n)
 
 
-@pytest.mark.parametrize("k,n", [(256, 512), (256, 64), (256, 192), (128, 256), (64, 512), (128, 384)])
+@pytest.mark.parametrize("k,n", [(256, 512), (256, 64), (256, 192), (128, 256), (64, 512), (128, 384),
+                                 (384, 128), (384, 64)])
 def test_wide_outputs_in_column_slices(dev, k, n):
-    """N > 128 and K = 256 (the 256 -> 512 projection of the wide-feature workload): column
-    slices computed by different workgroups, with bias, activation and row scale per slice."""
+    """N > 128 and K = 256, 384 (the 256 -> 512 projection of the wide-feature workload; the
+    gate gradients [rows, 3 x 128] times W_ih of a GRU layer's backward): column slices
+    computed by different workgroups, with bias, activation and row scale per slice."""
     assert nv.lib().spmi_gemm_rows_supported(k, n)
     gen = torch.Generator().manual_seed(k + n)
     for m in (1, 33, 5000 + 13):
