@@ -479,6 +479,45 @@ int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const f
                       const float* rest_packed, const int32_t* rest_out, const int32_t* rest_relu,
                       int32_t final_act, float* out, int64_t ldo, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Output head in training: the narrow [Linear, BatchNorm1d, ReLU, Dropout] blocks of the same
+ * MLP (simpleDecoder.py:60-72) with batch statistics, as the loop of
+ * examples/torch/citation_prediction.py:96-100 runs them, forward and backward; widths 1..32.
+ * The matrices between the layers (z = a Linear's output, its gradient dz, the gradient dy of a
+ * BatchNorm's output) are float32 [M, pad] with rows padded to pad = 8, 16 or 32 floats, the
+ * padding holding zeros, 16-byte aligned.  `stats` is 128 floats per BatchNorm: mean | rstd |
+ * scale = gamma * rstd | shift = beta - mean * scale (32 each, zero past the width).  `mask`
+ * (nullable) holds the dropout factors [M, wi] (0 or 1 / (1 - p)), unpadded.  Sums over rows are
+ * taken in a fixed order.  ws: spmi_mlp_train_workspace_bytes() bytes.
+ *   spmi_bn_col_stats      shifted column sums of a z that another kernel wrote -> ws, and z
+ *                          copied into rows of w_pad floats
+ *   spmi_bn_finalize       ws -> stats; moves running_mean / running_var (nullable) with
+ *                          `momentum` (unbiased variance), as BatchNorm1d.forward does.  pivot:
+ *                          row 0 of the matrix the sums were taken of
+ *   spmi_bn_act_linear_fwd out = Linear(dropout(relu(z * scale + shift))), W [wo_pad, wi_pad] and
+ *                          b [wo_pad] (nullable) zero-padded like the rows;
+ *                          ws_stats (nullable): the shifted column sums of out
+ *   spmi_bn_act_linear_bwd g = gradient of that out -> dy (gradient of the BatchNorm output)
+ *                          and sums[1120] = d beta [32] | d gamma [32] | db [32] | dW [32][32]
+ *   spmi_bn_bwd_apply      dz = scale * (dy - d beta / M - x_hat * d gamma / M)
+ * ---------------------------------------------------------------------- */
+size_t spmi_mlp_train_workspace_bytes(void);
+int spmi_bn_col_stats(const float* z /*[M, >= w_pad], row stride ldz*/, int64_t ldz, int64_t M,
+                      int64_t W, int64_t w_pad, float* packed /*[M, w_pad]: z, zero past W*/,
+                      float* ws, size_t ws_bytes, void* stream);
+int spmi_bn_finalize(const float* ws, const float* pivot, int64_t M, int64_t W, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* stats, void* stream);
+int spmi_bn_act_linear_fwd(const float* z, int64_t M, int64_t wi, int64_t wi_pad, const float* stats,
+                           const float* mask, const float* W, const float* b, int64_t wo,
+                           int64_t wo_pad, float* out, float* ws_stats, void* stream);
+int spmi_bn_act_linear_bwd(const float* z, int64_t M, int64_t wi, int64_t wi_pad, const float* stats,
+                           const float* mask, const float* W, int64_t wo, int64_t wo_pad,
+                           const float* g, float* dy, float* ws, size_t ws_bytes, float* sums,
+                           void* stream);
+int spmi_bn_bwd_apply(const float* dy, const float* z, int64_t M, int64_t W, int64_t w_pad,
+                      const float* stats, const float* sums, float* dz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

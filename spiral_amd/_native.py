@@ -89,6 +89,14 @@ _SIGNATURES = {
     "spmi_mlp_head_supported": (c_int, [c_i64, c_i32, c_i32, c_vp]),
     "spmi_mlp_head_fwd": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
                                   c_vp, c_i32, c_vp, c_i64, c_vp]),
+    "spmi_mlp_train_workspace_bytes": (c_sz, []),
+    "spmi_bn_col_stats": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "spmi_bn_finalize": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "spmi_bn_act_linear_fwd": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
+                                       c_vp, c_vp]),
+    "spmi_bn_act_linear_bwd": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp,
+                                       c_vp, c_sz, c_vp, c_vp]),
+    "spmi_bn_bwd_apply": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "spmi_cell_fused_supported": (c_int, [c_i64, c_i64]),
     "spmi_cell_fused_fwd": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),

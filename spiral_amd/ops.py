@@ -359,6 +359,158 @@ def pack_mlp_head(layers, device):
 
 
 # --------------------------------------------------------------------------- attention
+# ---- the output head in training ---------------------------------------------------------------
+
+MLP_TRAIN_MIN_ROWS = 4096
+
+
+def _pad_width(w: int) -> int:
+    return 8 if w <= 8 else (16 if w <= 16 else 32)
+
+
+def mlp_train_supported(in_width: int, widths) -> bool:
+    """The fused training path of the head takes it: a first Linear that spmi_gemm_rows runs
+    (its output padded to 32 columns) followed by blocks of widths <= 32."""
+    widths = list(widths)
+    return (len(widths) >= 2 and all(1 <= w <= 32 for w in widths)
+            and bool(nv.lib().spmi_gemm_rows_supported(in_width, 32))
+            and bool(nv.lib().spmi_gemm_rows_supported(32, in_width)))
+
+
+class MlpHeadTrain(torch.autograd.Function):
+    """x -> Linear_1 -> [BatchNorm (batch statistics) -> ReLU -> Dropout -> Linear_{p+1}] x k in
+    libspmi's row kernels (csrc/mlp_train.hip): the same numbers as the torch modules of
+    spiral_amd...simpleDecoder.MLP in train mode, a tenth of the launches.  Arguments: x
+    [rows, in]; masks: per block None or the dropout factors [rows, width] (0 or 1 / (1 - p));
+    bns: per block (eps, momentum, running_mean, running_var) with the running statistics
+    updated in place (None: not tracked); then the parameters W_1, b_1, gamma_1, beta_1, W_2,
+    b_2, ..., W_{k+1}, b_{k+1} (biases, gammas, betas may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, masks, bns, *params):
+        lib = nv.lib()
+        k = len(bns)
+        w = [params[4 * p] for p in range(k)] + [params[4 * k]]
+        b = [params[4 * p + 1] for p in range(k)] + [params[4 * k + 1]]
+        gamma = [params[4 * p + 2] for p in range(k)]
+        beta = [params[4 * p + 3] for p in range(k)]
+        m, dev = x.shape[0], x.device
+        widths = [t.shape[0] for t in w]
+        pads = [_pad_width(v) for v in widths]
+        xd = x.detach()
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        w_d, b_d = [f32(t) for t in w], [f32(t) for t in b]
+        with torch.cuda.device(dev):
+            ws_bytes = lib.spmi_mlp_train_workspace_bytes()
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            # z_1 = Linear_1(x) on the projection kernel, its weight padded to 32 output columns
+            w1 = torch.zeros(32, w_d[0].shape[1], dtype=torch.float32, device=dev)
+            w1[: widths[0]] = w_d[0]
+            b1 = torch.zeros(32, dtype=torch.float32, device=dev)
+            if b_d[0] is not None:
+                b1[: widths[0]] = b_d[0]
+            # the later weights and biases zero-padded to the row widths of the matrices around them
+            w_p, b_p = [None], [None]
+            for q in range(1, k + 1):
+                wq = torch.zeros(pads[q], pads[q - 1], dtype=torch.float32, device=dev)
+                wq[: widths[q], : widths[q - 1]] = w_d[q]
+                w_p.append(wq)
+                bq = None
+                if b_d[q] is not None:
+                    bq = torch.zeros(pads[q], dtype=torch.float32, device=dev)
+                    bq[: widths[q]] = b_d[q]
+                b_p.append(bq)
+            z1_wide = gemm_rows(xd, w1, b1)
+            zs = [torch.empty(m, pads[0], dtype=torch.float32, device=dev)]
+            stats = torch.zeros(k, 128, dtype=torch.float32, device=dev)
+            nv.check(lib.spmi_bn_col_stats(nv.ptr(z1_wide), 32, m, widths[0], pads[0], nv.ptr(zs[0]), nv.ptr(ws),
+                                           ws_bytes, nv.stream()), "spmi_bn_col_stats")
+            del z1_wide
+            for p in range(k):
+                eps, momentum, r_mean, r_var = bns[p]
+                nv.check(lib.spmi_bn_finalize(nv.ptr(ws), nv.ptr(zs[p]), m, widths[p], nv.ptr(f32(gamma[p])),
+                                              nv.ptr(f32(beta[p])), float(eps), float(momentum or 0.0),
+                                              nv.ptr(r_mean), nv.ptr(r_var), nv.ptr(stats[p]), nv.stream()),
+                         "spmi_bn_finalize")
+                out = torch.empty(m, pads[p + 1], dtype=torch.float32, device=dev)
+                last = p + 1 == k
+                nv.check(lib.spmi_bn_act_linear_fwd(nv.ptr(zs[p]), m, widths[p], pads[p], nv.ptr(stats[p]),
+                                                    nv.ptr(masks[p]), nv.ptr(w_p[p + 1]), nv.ptr(b_p[p + 1]),
+                                                    widths[p + 1], pads[p + 1], nv.ptr(out),
+                                                    None if last else nv.ptr(ws), nv.stream()),
+                         "spmi_bn_act_linear_fwd")
+                zs.append(out)
+        ctx.save_for_backward(xd, stats, w1, *zs[:-1], *[t for t in masks if t is not None], *w_p[1:])
+        ctx.layout = (k, widths, pads, [t is not None for t in masks], [t is not None for t in b],
+                      [t is not None for t in gamma], [t is not None for t in beta])
+        return zs[-1][:, : widths[-1]]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = nv.lib()
+        k, widths, pads, has_mask, has_b, has_gamma, has_beta = ctx.layout
+        saved = list(ctx.saved_tensors)
+        xd, stats, w1 = saved[:3]
+        zs = saved[3: 3 + k]
+        rest = saved[3 + k:]
+        masks = [rest.pop(0) if has_mask[p] else None for p in range(k)]
+        w_next = rest                                   # W_2 .. W_{k+1}
+        m, dev = xd.shape[0], xd.device
+        grads = [None] * (4 * k + 2)
+        with torch.cuda.device(dev):
+            ws_bytes = lib.spmi_mlp_train_workspace_bytes()
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            g = torch.zeros(m, pads[k], dtype=torch.float32, device=dev)
+            g[:, : widths[k]] = g_out
+            for p in range(k - 1, -1, -1):
+                dy = torch.empty(m, pads[p], dtype=torch.float32, device=dev)
+                sums = torch.empty(3 * 32 + 32 * 32, dtype=torch.float32, device=dev)
+                nv.check(lib.spmi_bn_act_linear_bwd(nv.ptr(zs[p]), m, widths[p], pads[p], nv.ptr(stats[p]),
+                                                    nv.ptr(masks[p]), nv.ptr(w_next[p]), widths[p + 1],
+                                                    pads[p + 1], nv.ptr(g), nv.ptr(dy), nv.ptr(ws), ws_bytes,
+                                                    nv.ptr(sums), nv.stream()), "spmi_bn_act_linear_bwd")
+                if ctx.needs_input_grad[3 + 4 * (p + 1)]:
+                    grads[4 * (p + 1)] = sums[96:].view(32, 32)[: widths[p + 1], : widths[p]].contiguous()
+                if has_b[p + 1] and ctx.needs_input_grad[3 + 4 * (p + 1) + 1]:
+                    grads[4 * (p + 1) + 1] = sums[64: 64 + widths[p + 1]].clone()
+                if has_gamma[p] and ctx.needs_input_grad[3 + 4 * p + 2]:
+                    grads[4 * p + 2] = sums[32: 32 + widths[p]].clone()
+                if has_beta[p] and ctx.needs_input_grad[3 + 4 * p + 3]:
+                    grads[4 * p + 3] = sums[: widths[p]].clone()
+                nv.check(lib.spmi_bn_bwd_apply(nv.ptr(dy), nv.ptr(zs[p]), m, widths[p], pads[p], nv.ptr(stats[p]),
+                                               nv.ptr(sums), nv.ptr(dy), nv.stream()), "spmi_bn_bwd_apply")
+                g = dy                                    # dz_p, in place of dy
+            # Linear_1: dz_1 [rows, pad] (zero past the width) against x
+            g_x = None
+            if ctx.needs_input_grad[0]:
+                if pads[0] == 32:
+                    g32 = g
+                else:
+                    g32 = torch.zeros(m, 32, dtype=torch.float32, device=dev)
+                    g32[:, : pads[0]] = g
+                g_x = gemm_rows(g32, w1.t().contiguous())
+            need_w1, need_b1 = ctx.needs_input_grad[3], has_b[0] and ctx.needs_input_grad[4]
+            g_w1, g_b1 = _weight_and_bias_grad(g[:, : widths[0]], xd, need_w1, need_b1, dy_first=True)
+            grads[0], grads[1] = g_w1, g_b1
+        return (g_x, None, None, *grads)
+
+
+def mlp_head_train(x: torch.Tensor, layers, masks) -> torch.Tensor:
+    """The training forward of a head made of `layers` = [(linear, batch_norm), ..., (linear, None)]
+    (torch modules) with the dropout factors `masks` (one per batch norm, None for no dropout);
+    differentiable in x and every parameter, running statistics updated as BatchNorm1d does."""
+    bns, params = [], []
+    for lin, bn in layers[:-1]:
+        tracked = bn.track_running_stats and bn.running_mean is not None
+        bns.append((bn.eps, bn.momentum, bn.running_mean if tracked else None,
+                    bn.running_var if tracked else None))
+        params += [lin.weight, lin.bias, bn.weight, bn.bias]
+        if tracked and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    params += [layers[-1][0].weight, layers[-1][0].bias]
+    return MlpHeadTrain.apply(x, list(masks), bns, *params)
+
+
 def _heavy(csr):
     return nv.ptr(csr.heavy_rows), csr.n_heavy, csr.heavy_thresh
 

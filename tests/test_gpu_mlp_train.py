@@ -1,0 +1,108 @@
+"""The output head in training on libspmi's row kernels (csrc/mlp_train.hip) against the same
+head as torch modules: [Linear, BatchNorm1d (batch statistics), ReLU, Dropout] blocks and a
+last Linear, forward, every gradient and the running statistics.  The reference is the torch
+module stack of spiro/dtdg/models/decoder/torch/simpleDecoder.py:60-72 evaluated in float64
+(with the dropout factors the fused path drew, and once with torch's own dropout under the same
+seed).  1e-5 relative to the largest entry of each tensor."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _fresh(in_dim, dims, dropout, dev, seed, activation="linear"):
+    torch.manual_seed(seed)
+    mine = MLP(in_dim, dims, dropout=dropout, activation=activation).to(dev)
+    with torch.no_grad():                      # statistics and affine parameters away from their defaults
+        for m in mine.layers:
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-1, 1)
+                m.running_var.uniform_(0.5, 2)
+    ref = copy.deepcopy(mine).cpu().double()
+    ref.FUSE_TRAIN = False
+    return mine, ref
+
+
+@pytest.mark.parametrize("rows,in_dim,dims", [(6000, 128, [10, 20, 10, 5]), (4100, 64, [32, 7]),
+                                              (5001, 128, [3])])
+def test_training_step_without_dropout(dev, rows, in_dim, dims):
+    mine, ref = _fresh(in_dim, dims, 0.0, dev, rows)
+    mine.train(), ref.train()
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, in_dim, generator=gen) * 2 + 0.5
+    wgt = torch.randn(rows, 1, generator=gen) * 1e-3
+    xa = x.to(dev).requires_grad_()
+    xb = x.double().requires_grad_()
+    assert mine._train_blocks(xa) is not None
+    out = mine((xa, None))
+    want = ref.mlp(xb)
+    assert out.shape == want.shape and _rel(out, want) < 1e-5
+    (out * wgt.to(dev)).sum().backward()
+    (want * wgt.double()).sum().backward()
+    assert _rel(xa.grad, xb.grad) < 1e-5
+    for (name, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, name
+        # a Linear bias in front of a batch norm has a zero gradient: both sides hold rounding noise
+        if q.grad.abs().max() < 1e-9 * wgt.abs().max() * rows:
+            assert float(p.grad.abs().max()) < 1e-5 * float(wgt.abs().sum()), name
+            continue
+        assert _rel(p.grad, q.grad) < 1e-5, name
+    for (name, p), (_, q) in zip(mine.named_buffers(), ref.named_buffers()):
+        assert _rel(p, q) < 1e-5, name
+    # a second step reuses nothing stale
+    out2 = mine((xa.detach() * 0.5, None))
+    want2 = ref.mlp(xb.detach() * 0.5)
+    assert _rel(out2, want2) < 1e-5
+
+
+def test_dropout_factors_come_from_torchs_generator(dev):
+    """Same seed, same masks as the torch modules draw: the fused head and the module stack (in
+    float32 on the GPU, where the generator lives) agree through dropout."""
+    rows, in_dim, dims = 8192, 128, [10, 20, 10, 5]
+    mine, _ = _fresh(in_dim, dims, 0.5, dev, 3)
+    ref = copy.deepcopy(mine)
+    ref.FUSE_TRAIN = False
+    mine.train(), ref.train()
+    x = torch.randn(rows, in_dim, device=dev)
+    wgt = torch.randn(rows, 1, device=dev) * 1e-3
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    torch.manual_seed(77)
+    out = mine((xa, None))
+    torch.manual_seed(77)
+    want = ref((xb, None))
+    assert _rel(out, want) < 1e-5
+    (out * wgt).sum().backward()
+    (want * wgt).sum().backward()
+    assert _rel(xa.grad, xb.grad) < 1e-4
+    for (name, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        if float(q.grad.abs().max()) > 1e-7:
+            assert _rel(p.grad, q.grad) < 1e-4, name
+
+
+def test_falls_back_where_it_does_not_apply(dev):
+    mine, _ = _fresh(128, [10, 5], 0.0, dev, 0)
+    mine.train()
+    x = torch.randn(5000, 128, device=dev)
+    assert mine._train_blocks(x) is not None
+    assert mine._train_blocks(x[:100]) is None                 # few rows: torch modules
+    with torch.no_grad():
+        assert mine._train_blocks(x) is None
+    mine.eval()
+    assert mine._train_blocks(x) is None
+    wide, _ = _fresh(128, [64, 5], 0.0, dev, 0)                # a layer wider than 32
+    wide.train()
+    assert wide._train_blocks(x) is None
+    out = wide((x, None))
+    assert out.shape == (5000, 1)
