@@ -36,7 +36,7 @@ def _fresh(in_dim, dims, dropout, dev, seed, activation="linear"):
 
 
 @pytest.mark.parametrize("rows,in_dim,dims", [(6000, 128, [10, 20, 10, 5]), (4100, 64, [32, 7]),
-                                              (5001, 128, [3])])
+                                              (5001, 128, [3]), (4500, 32, [24, 30, 17])])
 def test_training_step_without_dropout(dev, rows, in_dim, dims):
     mine, ref = _fresh(in_dim, dims, 0.0, dev, rows)
     mine.train(), ref.train()
