@@ -115,3 +115,31 @@ def test_bf16_pieces_keep_fp32_range_and_accuracy(dev):
         finally:
             ops.GEMM_TN_MODE = old
     assert errs["bf16x3"] < 1e-5 and errs["bf16x3"] < 4 * errs["fp32"] + 1e-7, errs
+
+
+@pytest.mark.parametrize("k", [1, 5, 16, 17, 31, 48, 300, 4101])
+def test_whole_block_kernel_at_short_and_ragged_k(dev, k):
+    """Straight through the C-ABI (the Python wrapper sends short matrices to the library):
+    128 x 128 and 256 x 128 outputs, i.e. the kernel that owns whole blocks, for reductions
+    shorter than one K-step, ending inside a step, and with an odd number of steps; leading
+    dimensions wider than the operands; column sums included."""
+    lib = nv.lib()
+    rng = np.random.default_rng(k)
+    for m, n in ((128, 128), (256, 128)):
+        big_a = rng.standard_normal((k, m + 4)).astype(np.float32)
+        big_b = rng.standard_normal((k, n + 8)).astype(np.float32)
+        ta, tb = torch.from_numpy(big_a).to(dev), torch.from_numpy(big_b).to(dev)
+        a, b = ta[:, 4:], tb[:, :n]                       # 16-byte aligned column ranges
+        c = torch.empty(m, n, device=dev)
+        sa, sb = torch.empty(m, device=dev), torch.empty(n, device=dev)
+        nbytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nv.check(lib.spmi_gemm_tn_sums(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n, nv.ptr(c), n, 0,
+                                       nv.ptr(sa), nv.ptr(sb), 0, nv.ptr(ws), nbytes, nv.stream()),
+                 "spmi_gemm_tn_sums")
+        want = big_a[:, 4:].astype(np.float64).T @ big_b[:, :n].astype(np.float64)
+        scale = np.abs(big_a[:, 4:]).astype(np.float64).T @ np.abs(big_b[:, :n]).astype(np.float64)
+        assert (np.abs(c.cpu().numpy() - want) / scale).max() < 1e-5, (k, m, n)
+        for got, ref in ((sa, big_a[:, 4:]), (sb, big_b[:, :n])):
+            err = np.abs(got.cpu().numpy() - ref.astype(np.float64).sum(0))
+            assert (err / np.abs(ref).astype(np.float64).sum(0)).max() < 1e-5, (k, m, n)
