@@ -5,7 +5,7 @@ libspmi; the kernels themselves are checked in the -m gpu tests).  What is under
 edge-balanced block bounds, the exchange plan (which rows travel where, the compact source
 table and its column numbering, batches), the all-to-all of the needed rows and its reverse
 in the backward pass, the out-degree all-reduce and the gradient all-reduce.  The sharded
-result must equal the single-process oracle, for 2 and 3 ranks and 1 to 3 batches."""
+result must equal the single-process oracle, for 2 to 4 ranks and 1 to 3 batches."""
 import os
 import socket
 from types import SimpleNamespace
@@ -122,7 +122,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,fi,fo,act,stages", [(2, 12, 6, "relu", 1), (2, 8, 8, None, 2),
-                                                    (3, 8, 12, "relu", 3), (3, 12, 6, None, 1)])
+                                                    (3, 8, 12, "relu", 3), (3, 12, 6, None, 1),
+                                                    (4, 8, 8, "relu", 2)])
 def test_sharded_graphconv_equals_single_process(world, fi, fo, act, stages):
     with mp.Manager() as mgr:
         results = mgr.dict()
