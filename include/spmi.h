@@ -380,6 +380,14 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
  * GraphConv.forward) without a pass of its own or a per-edge weight.
  * ---------------------------------------------------------------------- */
 int spmi_gemm_rows_supported(int64_t K, int64_t N);
+/* The same projection for x stored as bfloat16 (bf16 feature storage of EvolveGCN-O): x is an
+ * operand as it is, w_pieces = spmi_split_bf16x3(W, N, K) keeps the weight at fp32 accuracy
+ * (three products per term), out is bfloat16 (out_bf16 = 1, rounded once) or float32.  K in
+ * {32, 64, 128}, N in {32, 64, 96, 128}; ldx (elements) a multiple of 8. */
+int spmi_gemm_rows_bf16_supported(int64_t K, int64_t N);
+int spmi_gemm_rows_bf16(const void* x /*device bf16 [M, K]*/, int64_t ldx, int64_t M, int64_t K,
+                        const void* w_pieces, int64_t N, const float* bias, const float* row_scale,
+                        int act, float slope, void* out, int64_t ldo, int out_bf16, void* stream);
 int spmi_gemm_rows(const float* x /*device [M, K], row stride ldx*/, int64_t ldx, int64_t M, int64_t K,
                    const void* w_planes, int64_t N, const float* bias /*device [N] or null*/,
                    const float* row_scale /*device [M] or null*/, int act, float slope,

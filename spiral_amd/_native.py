@@ -66,6 +66,9 @@ _SIGNATURES = {
                                     c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
     "spmi_split_f16x3": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "spmi_gemm_rows_supported": (c_int, [c_i64, c_i64]),
+    "spmi_gemm_rows_bf16_supported": (c_int, [c_i64, c_i64]),
+    "spmi_gemm_rows_bf16": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_f32, c_vp, c_i64,
+                                    c_int, c_vp]),
     "spmi_gemm_rows": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_f32, c_vp,
                                c_i64, c_vp]),
     "spmi_cell_f16x3_fwd": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -237,6 +237,207 @@ int launch(const RowsArgs& a, hipStream_t st) {
   return SPMI_OK;
 }
 
+// ---- rows stored as bfloat16 -------------------------------------------------------------------
+// The same projection for feature matrices kept in bfloat16 (EvolveGCN-O's storage option,
+// spiro's staticGraphEncoder.py:113,116 call sites with half the feature bytes).  A bfloat16
+// value IS a matrix-core operand: the eight consecutive k of a lane's row are one 16-byte
+// load, with no split and no scaling (fp32's exponent range).  The weight stays an fp32
+// quantity: its three exact bf16 pieces (spmi_split_bf16x3) give three products per term,
+// x * w to fp32 accuracy, where a bfloat16 library GEMM rounds the weight to 8 bits first.
+// Results leave as bfloat16 (rounded once, to nearest even) or float32.
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+struct RowsBf16Args {
+  const uint16_t* x;  // bfloat16 [M, K], row stride ldx (elements)
+  int64_t ldx;
+  int64_t M;
+  const uint4* wp;  // weight pieces, [KT][3][2][N][8] bfloat16
+  const float* bias;
+  const float* row_scale;
+  int act;
+  float slope;
+  void* out;  // bfloat16 or float32 [M, N], row stride ldo (elements)
+  int64_t ldo;
+  int out_bf16;
+};
+
+template <int KT, int NB>
+__global__ __launch_bounds__(512, 2) void gemm_rows_bf16_kernel(RowsBf16Args p) {
+  constexpr int NW = 8;
+  constexpr int N = NB * 32;
+  constexpr int PLANE = N * 32;
+  constexpr int KSTEP = 3 * PLANE;
+  constexpr int B16 = KT * KSTEP / 16;
+  extern __shared__ uint4 smem4[];
+  const char* smem = reinterpret_cast<const char*>(smem4);
+  const int tid = threadIdx.x;
+  // K order (KT a multiple of 4): a lane reads 64 contiguous bytes of its row at a time, four
+  // 16-byte loads back to back that feed four K-steps, and the two lane halves share a
+  // 128-byte line, which is then fetched from L2 once: K-step 4u + v, lane half lh, slot i
+  // stands for k = 64 u + 32 lh + 8 v + i.  The weight image is permuted to match: LDS
+  // (step 4u + v, half lh) <- source (step 4u + 2 lh + v / 2, half v % 2).
+  constexpr bool GROUPED = KT % 4 == 0;
+  for (int c = tid; c < B16; c += NW * 64) {
+    int src = c;
+    if constexpr (GROUPED) {
+      const int n = c % N, hh = (c / N) & 1, q = (c / (2 * N)) % 3, t = c / (6 * N);
+      const int s_ = (t & ~3) + 2 * hh + ((t & 3) >> 1), h_ = t & 1;
+      src = ((s_ * 3 + q) * 2 + h_) * N + n;
+    }
+    smem4[c] = p.wp[src];
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t n_tiles = (p.M + 31) / 32;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
+  if (tile >= n_tiles) return;
+
+  float bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bias[nb] = p.bias ? p.bias[nb * 32 + lr] : 0.0f;
+
+  // Rows past M are clamped to the last row: computed, never stored.
+  auto row_ptr = [&](int64_t t) {
+    int64_t r = t * 32 + lr;
+    r = r < p.M ? r : p.M - 1;
+    return p.x + r * p.ldx + (GROUPED ? 32 : 8) * lh;
+  };
+  // element offset of K-step t inside the lane's share of the row
+  auto k_off = [](int t) { return GROUPED ? 64 * (t >> 2) + 8 * (t & 3) : 16 * t; };
+  uint4 a[KT];
+  {
+    const uint16_t* src = row_ptr(tile);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) a[t] = *reinterpret_cast<const uint4*>(src + k_off(t));
+  }
+  const int b_rd = (lh * N + lr) * 16;
+
+  while (tile < n_tiles) {
+    const int64_t next = tile + stride;
+    // the last iteration re-reads its own tile: valid memory, nothing is done with it
+    const uint16_t* src = row_ptr(next < n_tiles ? next : tile);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nb][e] = 0.0f;
+    float rs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int64_t r = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      r = r < p.M ? r : p.M - 1;
+      rs[e] = p.row_scale ? p.row_scale[r] : 1.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      union { uint4 u; bf16x8 v; } av;
+      av.u = a[t];
+      if constexpr (GROUPED) {
+        // the next tile's rows, a 64-byte span at a time, into the registers of the four
+        // K-steps that have just been used (K-step t itself is in `av`)
+        if ((t & 3) == 3) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) a[t - 3 + v] = *reinterpret_cast<const uint4*>(src + k_off(t - 3 + v));
+        }
+      } else {
+        a[t] = *reinterpret_cast<const uint4*>(src + k_off(t));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sb = smem + t * KSTEP + b_rd;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 hi = *reinterpret_cast<const bf16x8*>(sb + nb * 32 * 16);
+        const bf16x8 mid = *reinterpret_cast<const bf16x8*>(sb + nb * 32 * 16 + PLANE);
+        const bf16x8 lo = *reinterpret_cast<const bf16x8*>(sb + nb * 32 * 16 + 2 * PLANE);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.v, lo, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.v, mid, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.v, hi, acc[nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int64_t row0 = tile * 32;
+    if (p.out_bf16) {
+      // The accumulator layout gives a lane one column of sixteen rows: stored from there, a
+      // tile is 64 NB two-byte stores per lane.  The wave's 32 x N results go through an LDS
+      // area of its own instead and leave as 16-byte pieces of whole rows.
+      __bf16* stage = reinterpret_cast<__bf16*>(smem4) + (static_cast<size_t>(KT) * KSTEP) / 2 + wave * 32 * N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float v = acc[nb][e] + bias[nb];
+          if (p.act == 1) v = fmaxf(v, 0.0f);
+          else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
+          stage[ur * N + nb * 32 + lr] = static_cast<__bf16>(v * rs[e]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int PER_ROW = N / 8;            // 16-byte pieces of a row
+      constexpr int PIECES = 32 * PER_ROW / 64;  // per lane
+      __bf16* obase = static_cast<__bf16*>(p.out);
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) {
+        const int piece = q * 64 + lane;
+        const int ur = piece / PER_ROW, c8 = piece % PER_ROW;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + ur * N + c8 * 8);
+        if (row0 + ur < p.M) *reinterpret_cast<uint4*>(obase + (row0 + ur) * p.ldo + c8 * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t r = row0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (r >= p.M) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float v = acc[nb][e] + bias[nb];
+          if (p.act == 1) v = fmaxf(v, 0.0f);
+          else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
+          static_cast<float*>(p.out)[r * p.ldo + nb * 32 + lr] = v * rs[e];
+        }
+      }
+    }
+    tile = next;
+  }
+}
+
+template <int KT, int NB>
+int launch_bf16(const RowsBf16Args& a, hipStream_t st) {
+  // weight image + a 32 x N bfloat16 output area per wave
+  constexpr size_t lds = static_cast<size_t>(KT) * 3 * NB * 32 * 32 + 8 * 32 * NB * 32 * 2;
+  static_assert(lds <= 160 * 1024, "weight image and output areas do not fit LDS");
+  auto kern = gemm_rows_bf16_kernel<KT, NB>;
+  static bool configured = false;
+  if (!configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const int64_t n_tiles = (a.M + 31) / 32;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  int64_t blocks = (n_tiles + 7) / 8;
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+  kern<<<static_cast<unsigned>(blocks), 512, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("gemm_rows_bf16");
+  return SPMI_OK;
+}
+
+template <int KT>
+int launch_bf16_n(const RowsBf16Args& a, int64_t N, hipStream_t st) {
+  switch (N) {
+    case 32: return launch_bf16<KT, 1>(a, st);
+    case 64: return launch_bf16<KT, 2>(a, st);
+    case 96: return launch_bf16<KT, 3>(a, st);
+    default: return launch_bf16<KT, 4>(a, st);
+  }
+}
+
 // Columns per workgroup: the whole weight up to 128 columns, slices of 128 (K <= 128) or 64
 // (K = 256, 384) beyond.
 int slice_width(int64_t K, int64_t N) {
@@ -269,6 +470,36 @@ extern "C" {
 int spmi_gemm_rows_supported(int64_t K, int64_t N) {
   if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 384) || N < 32 || N > 4096) return 0;
   return slice_width(K, N) != 0;
+}
+
+int spmi_gemm_rows_bf16_supported(int64_t K, int64_t N) {
+  return (K == 32 || K == 64 || K == 128) && N >= 32 && N <= 128 && N % 32 == 0;
+}
+
+int spmi_gemm_rows_bf16(const void* x, int64_t ldx, int64_t M, int64_t K, const void* w_pieces, int64_t N,
+                        const float* bias, const float* row_scale, int act, float slope, void* out,
+                        int64_t ldo, int out_bf16, void* stream) {
+  SPMI_REQUIRE(spmi_gemm_rows_bf16_supported(K, N), SPMI_ERR_UNSUPPORTED,
+               "spmi_gemm_rows_bf16: K must be 32, 64 or 128 and N 32..128 in steps of 32 (K=%lld N=%lld)",
+               (long long)K, (long long)N);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gemm_rows_bf16: bad M=%lld",
+               (long long)M);
+  SPMI_REQUIRE(act >= 0 && act <= 2, SPMI_ERR_INVALID_ARG, "spmi_gemm_rows_bf16: bad act %d", act);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(x && w_pieces && out && ldx >= K && ldx % 8 == 0 && ldo >= N, SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_rows_bf16: null pointer or bad leading dimension (ldx a multiple of 8)");
+  SPMI_REQUIRE(!out_bf16 || (ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0), SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_rows_bf16: a bfloat16 result needs ldo a multiple of 8 and a 16-byte aligned pointer");
+  SPMI_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(w_pieces) & 15u) == 0,
+               SPMI_ERR_INVALID_ARG, "spmi_gemm_rows_bf16: x and w_pieces must be 16-byte aligned");
+  RowsBf16Args a{};
+  a.x = static_cast<const uint16_t*>(x); a.ldx = ldx; a.M = M; a.wp = static_cast<const uint4*>(w_pieces);
+  a.bias = bias; a.row_scale = row_scale; a.act = act; a.slope = slope; a.out = out; a.ldo = ldo;
+  a.out_bf16 = out_bf16;
+  hipStream_t st = spmi::as_stream(stream);
+  if (K == 32) return launch_bf16_n<2>(a, N, st);
+  if (K == 64) return launch_bf16_n<4>(a, N, st);
+  return launch_bf16_n<8>(a, N, st);
 }
 
 int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void* w_planes, int64_t N,

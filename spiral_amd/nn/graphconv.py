@@ -89,14 +89,15 @@ class GraphConv(WeightCacheHooks, nn.Module):
 
         code, slope, unfused = _classify_activation(self._activation)
 
-        if weight is not None and weight.dtype != feat.dtype:
-            weight = weight.to(feat.dtype)  # bf16 feature storage: the projection runs in bf16
         tracked = torch.is_grad_enabled() and (feat.requires_grad or (weight is not None and weight.requires_grad)
                                                or (self.bias is not None and self.bias.requires_grad))
         rst = None
         if (self._in_feats >= self._out_feats and weight is not None and edge_weight is None and not tracked
-                and feat.dtype == torch.float32):
+                and feat.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32):
+            # bfloat16 rows against the float32 weight: spmi_gemm_rows_bf16 keeps the weight's value
             rst = graphconv_inference(graph, feat, weight, self._norm, self.bias, code, slope)
+        if weight is not None and weight.dtype != feat.dtype:
+            weight = weight.to(feat.dtype)  # bf16 feature storage on the library path: the projection runs in bf16
         if rst is not None:
             pass
         elif self._in_feats >= self._out_feats:

@@ -181,6 +181,36 @@ def gemm_rows(x: torch.Tensor, weight_nk: torch.Tensor, bias: Optional[torch.Ten
     return out
 
 
+def _gemm_rows_bf16_ok(x: torch.Tensor, k: int, n: int) -> bool:
+    return (DENSE_GEMM == "f16x3" and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2
+            and x.shape[0] >= GEMM_ROWS_MIN_ROWS and x.shape[1] == k and x.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and bool(nv.lib().spmi_gemm_rows_bf16_supported(k, n)))
+
+
+def gemm_rows_bf16(x: torch.Tensor, pieces: torch.Tensor, n: int, bias: Optional[torch.Tensor] = None,
+                   act: Optional[str] = None, slope: float = 0.01,
+                   row_scale: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16
+                   ) -> torch.Tensor:
+    """act(x @ W.T + bias) * row_scale[:, None] for x [rows, K] stored as bfloat16 and a float32
+    weight W [N, K] given as its three bf16 pieces (`weight_planes(..., "bf16x3", ...)`): one
+    launch of spmi_gemm_rows_bf16, products at fp32 accuracy, result rounded once to `out_dtype`
+    (bfloat16 or float32).  The caller has checked `_gemm_rows_bf16_ok(x, K, N)`."""
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise nv.SpmiError("gemm_rows_bf16: out_dtype must be bfloat16 or float32")
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    if row_scale is not None and (row_scale.dtype != torch.float32 or row_scale.numel() != x.shape[0]
+                                  or not row_scale.is_contiguous()):
+        raise nv.SpmiError("gemm_rows_bf16: row_scale must be a contiguous float32 vector with one entry per row")
+    with torch.cuda.device(x.device):
+        out = torch.empty(x.shape[0], n, dtype=out_dtype, device=x.device)
+        nv.check(nv.lib().spmi_gemm_rows_bf16(nv.ptr(x), x.stride(0), x.shape[0], x.shape[1], nv.ptr(pieces), n,
+                                              nv.ptr(b), nv.ptr(row_scale), _ACT_CODES[act], float(slope),
+                                              nv.ptr(out), n, int(out_dtype == torch.bfloat16), nv.stream()),
+                 "spmi_gemm_rows_bf16")
+    return out
+
+
 def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
                         bias: Optional[torch.Tensor], act: Optional[str], slope: float
                         ) -> Optional[torch.Tensor]:
@@ -188,12 +218,20 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
     normaliser is applied to the projected rows in the GEMM's epilogue (as DGL does with
     `feat_src * norm`), so the aggregation needs no per-edge weight and the snapshot no
     gather of one.  Returns None when the shapes are not covered."""
-    if norm not in ("both", "left", "right", "none") or not _gemm_rows_ok(feat, weight.shape[0], weight.shape[1]):
+    if norm not in ("both", "left", "right", "none"):
+        return None
+    bf16 = feat.dtype == torch.bfloat16
+    if not (_gemm_rows_bf16_ok if bf16 else _gemm_rows_ok)(feat, weight.shape[0], weight.shape[1]):
         return None
     mode = 0 if norm == "both" else 1
     scale = g.norm("out", mode) if norm in ("both", "left") else None
-    rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale,
-                    planes=weight_planes(weight, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
+    if bf16:
+        # bfloat16 feature storage: the rows are matrix-core operands as they are, the weight
+        # keeps its float32 value (three exact bf16 pieces), the projected rows are rounded once
+        rst = gemm_rows_bf16(feat, weight_planes(weight, "bf16x3", True), weight.shape[1], None, None, 0.01, scale)
+    else:
+        rst = gemm_rows(feat, weight.detach().t(), None, None, 0.01, scale,
+                        planes=weight_planes(weight, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
     dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
     return aggregate(g.csr(wait=False), rst, None, None, dst_scale,
                      None if bias is None else bias.detach(), act, slope)

@@ -244,3 +244,30 @@ def test_weight_beyond_the_fp16_plane_domain_is_reported(dev):
         torch.cuda.synchronize()
         with pytest.raises(nv.SpmiError, match="domain"):
             ops.rows_times_weight(x, w)
+
+
+@pytest.mark.parametrize("k,n", [(128, 128), (64, 96), (32, 32)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_rows_stored_as_bfloat16(dev, k, n, out_dtype):
+    """spmi_gemm_rows_bf16: bfloat16 rows (exact operands) against the float32 weight kept as
+    three bf16 pieces.  Reference: float64 on the stored row values; a float32 result is within
+    1e-5 of the scale, a bfloat16 one within bfloat16's own rounding (2^-8) of it, where a
+    bfloat16 GEMM would have rounded the weight as well."""
+    assert nv.lib().spmi_gemm_rows_bf16_supported(k, n) and not nv.lib().spmi_gemm_rows_bf16_supported(256, 128)
+    gen = torch.Generator().manual_seed(k * n)
+    for m in (4096, 5000 + 13):
+        x = (torch.randn(m, k, generator=gen) * 2).to(torch.bfloat16).to(dev)
+        w = (torch.randn(n, k, generator=gen) * 0.1).to(dev)
+        b = torch.randn(n, generator=gen).to(dev)
+        rs = (torch.rand(m, generator=gen) + 0.5).to(dev)
+        pieces = ops.split_bf16x3(w)
+        got = ops.gemm_rows_bf16(x, pieces, n, b, "leaky_relu", 0.01, rs, out_dtype)
+        pre = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+        want = torch.where(pre > 0, pre, pre * 0.01) * rs.double().cpu()[:, None]
+        assert got.dtype == out_dtype and got.shape == (m, n)
+        err = (got.double().cpu() - want).abs()
+        if out_dtype == torch.float32:
+            assert float(err.max()) < 1e-5 * float(want.abs().max())
+        else:
+            # one rounding to bfloat16 on top of the float32 sum's own 1e-5 of the scale
+            assert bool((err <= want.abs() * 2.0 ** -8 + 1e-5 * float(want.abs().max())).all())
