@@ -313,11 +313,14 @@ def main():
     # SPMI_BENCH_REHEARSE=1: every rank on cuda:0 over gloo, to walk the multi-rank code path
     # on a one-GPU box (not a measurement; RCCL needs one device per rank).
     rehearse = os.environ.get("SPMI_BENCH_REHEARSE") == "1"
+    # SPMI_BENCH_ONE_RANK_DIST=1: a single rank takes the multi-rank code path over its real
+    # communicator (RCCL with one member): what a one-GPU box can check of that path's calls.
+    multi = world > 1 or os.environ.get("SPMI_BENCH_ONE_RANK_DIST") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         if rehearse:
             dist.init_process_group("gloo")
             _stage_collectives_through_host()
@@ -334,7 +337,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(99)
     perm = torch.randperm(n_total, generator=gen, device=dev)
-    if world > 1:
+    if multi:
         dist.broadcast(perm, src=0)  # one permutation for all ranks, whatever their generators do
         src0, dst0 = gen_snapshot(n_total, e_total, 0, w["k_dst"], w["k_src"], perm, dev)
         bounds = [par.edge_balanced_bounds(G.degree(dst0, n_total), world)]
@@ -348,7 +351,7 @@ def main():
     snapshots = []
     for t in range(n_snap):
         src, dst = gen_snapshot(n_total, e_total, t, w["k_dst"], w["k_src"], perm, dev)
-        if world > 1:
+        if multi:
             keep = (dst >= lo) & (dst < hi)
             src, dst = src[keep].contiguous(), dst[keep].contiguous()
         snapshots.append((src, dst))
@@ -356,13 +359,13 @@ def main():
     x_local = torch.randn(n_local, f, generator=gen, device=dev)
     torch.manual_seed(11)
     kind = w.get("model", "gcn_gru")
-    if kind != "gcn_gru" and world > 1:
+    if kind != "gcn_gru" and multi:
         raise SystemExit(f"workload {args.workload} is single-GPU in this bench")
     model = Path(f, w["hidden"], w["rnn_hidden"], n_local, dev, kind)
     if kind == "evolve_bf16":
         x_local = x_local.to(torch.bfloat16)
     ids = identity_ids(n_local, dev)
-    pipelined = world > 1 and args.mode == "forward" and args.exchange == "pipelined"
+    pipelined = multi and args.mode == "forward" and args.exchange == "pipelined"
     payload = torch.bfloat16 if args.gather_dtype == "bf16" else None
     n_stages = args.stages or (1 if pipelined else 4)
     if pipelined:
@@ -402,7 +405,7 @@ def main():
                 ev[4].record()
                 stage_events.append(ev)
             return h
-        if world == 1:
+        if not multi:
             g = G.SnapshotGraph(src, dst, n_total)
             g.csr(wait=False)  # the first aggregation collects the build's status word
             g.norm("in", 0)
@@ -481,7 +484,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -506,7 +509,7 @@ def main():
         # parameter gradients are the gradient of the whole snapshot's loss
         loss = F.mse_loss(step(i, record).squeeze(-1), label, reduction="sum") / n_total
         loss.backward()
-        if world > 1:
+        if multi:
             par.allreduce_gradients(model)
         opt.step()
         return loss
@@ -546,7 +549,7 @@ def main():
     elapsed = time.perf_counter() - t0
     G.set_launch_log(None)
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -700,7 +703,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -17,3 +17,10 @@ run 2 --exchange plain
 run 2 --exchange plain --scaling strong --stages 2
 run 3 --exchange pipelined --scaling strong --gather-dtype bf16 --stages 2
 run 2 --mode train
+# one rank over RCCL itself: the multi-rank code path with its real communicator
+unset SPMI_BENCH_REHEARSE
+export SPMI_BENCH_ONE_RANK_DIST=1
+run 1 --exchange pipelined
+run 1 --exchange plain --scaling strong --stages 2
+run 1 --exchange pipelined --gather-dtype bf16
+run 1 --mode train

@@ -1,8 +1,8 @@
 """The row-partitioned GraphConv with the real kernels: two ranks share the one GPU of the
 test box and exchange through gloo with host staging (RCCL needs a device per rank, so
-the collectives themselves are not under test here, only everything around them: the
-exchange plan, the compact source tables, the batch-by-batch aggregation, the halves of a
-layer with the exchange in flight across snapshots).  Sharded forward and backward must equal
+what is under test there is everything around the collectives: the exchange plan, the compact
+source tables, the batch-by-batch aggregation, the halves of a layer with the exchange in
+flight across snapshots); a one-rank case runs the same code over RCCL itself.  Sharded forward and backward must equal
 the single-GPU layer; a second case runs the inference pipeline at 1M nodes x 10M edges."""
 import os
 import socket
@@ -73,14 +73,19 @@ def _two_layers(fi, dev):
     return conv1, conv2
 
 
-def _worker(rank, world, port, stages, results):
+def _worker(rank, world, port, stages, backend, results):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from spiral_amd import graph as G
         from spiral_amd import parallel as par
 
-        _stage_through_host()
+        if backend == "gloo":
+            _stage_through_host()
         dev = torch.device("cuda:0")
         n, src, dst, x, w, b = _problem()
         src_t, dst_t = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
@@ -154,12 +159,14 @@ def rel(a, ref):
     return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
 
 
-@pytest.mark.parametrize("stages", [1, 3])
-def test_two_ranks_on_one_gpu_equal_single_gpu(dev, stages):
+@pytest.mark.parametrize("world,stages,backend", [(2, 1, "gloo"), (2, 3, "gloo"), (1, 2, "nccl")])
+def test_ranks_on_one_gpu_equal_single_gpu(dev, world, stages, backend):
+    """Two ranks over gloo, and one rank over RCCL: the library's own collectives (all-to-all
+    with per-peer counts, all-reduce, a second communicator, bfloat16 payload, asynchronous
+    handles) as the multi-GPU path calls them, on the one device a test box has."""
     from spiral_amd.graph import SnapshotGraph
 
-    world = 2
-    results = _spawn(_worker, world, stages)
+    results = _spawn(_worker, world, stages, backend)
     n, src, dst, x, w, b = _problem()
     g = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
     conv = _layer(x.shape[1], w.shape[1], w, b, dev)
@@ -170,7 +177,8 @@ def test_two_ranks_on_one_gpu_equal_single_gpu(dev, stages):
     bounds = results[0]["bounds"]
     for r in range(world):
         lo, hi = bounds[r], bounds[r + 1]
-        assert 0 < results[r]["n_remote"] < n - (hi - lo)       # fewer rows than an all-gather moves
+        if world > 1:
+            assert 0 < results[r]["n_remote"] < n - (hi - lo)   # fewer rows than an all-gather moves
         assert rel(results[r]["y"], y[lo:hi]) < 1e-5
         assert rel(results[r]["y_ng"], y[lo:hi]) < 1e-5
         assert rel(results[r]["gx"], xg.grad[lo:hi]) < 1e-5
