@@ -83,9 +83,15 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   const int col0 = slice * N;
 
   const int tid = threadIdx.x;
-  // image [K-step][plane][k half][n_total][8]: 16-byte chunk index ((t*3+q)*2+h) * n_total + n
+  // image [K-step][plane][k half][n_total][8]: 16-byte chunk index ((t*3+q)*2+h) * n_total + n.
+  // K order: a lane reads 64 contiguous bytes of its row at a time (half of a 128-byte line,
+  // four loads back to back, so the line is fetched from L2 once), which feed two K-steps:
+  // K-step 2u + v, lane half lh, slot i stands for k = 32 u + 16 lh + 8 v + i.  The image is
+  // permuted to match: LDS (step 2u + v, half lh) <- source (step 2u + lh, half v).
+  static_assert(KT % 2 == 0, "K-steps come in pairs");
   for (int c = tid; c < B16; c += NW * 64) {
-    const int n = c % N, rest = c / N;
+    const int n = c % N, hh = (c / N) & 1, q = (c / (2 * N)) % 3, t = c / (6 * N);
+    const int rest = (((t & ~1) + hh) * 3 + q) * 2 + (t & 1);
     smem4[c] = p.wp[static_cast<size_t>(rest) * p.n_total + col0 + n];
   }
   __syncthreads();
@@ -107,17 +113,23 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   auto row_ptr = [&](int64_t t) {
     int64_t r = t * 32 + lr;
     r = r < p.M ? r : p.M - 1;
-    return p.x + r * p.ldx + 8 * lh;
+    return p.x + r * p.ldx + 16 * lh;
   };
 
+  // a[t][0..1]: the eight values of K-step t; the four float4 of a[2u], a[2u+1] are 64
+  // contiguous bytes
   float4 a[KT][2];
+  auto load_pair = [&](const float* src, int u) {
+    const float4* q = reinterpret_cast<const float4*>(src + 32 * u);
+    a[2 * u][0] = q[0];
+    a[2 * u][1] = q[1];
+    a[2 * u + 1][0] = q[2];
+    a[2 * u + 1][1] = q[3];
+  };
   {
     const float* src = row_ptr(tile);
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
-      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
-    }
+    for (int u = 0; u < KT / 2; ++u) load_pair(src, u);
   }
   const int b_rd = (lh * N + lr) * 16;  // [plane][k half][n][8]: 512 contiguous bytes per half
 
@@ -169,8 +181,7 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
         hi.x *= up; hi.y *= up; hi.z *= up; hi.w *= up;
         split8(lo, hi, p0, p1, p2);
       }
-      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
-      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+      if (t & 1) load_pair(src, t >> 1);
       // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
       // the tile and then needs a second copy of the whole row in registers.
       __builtin_amdgcn_sched_barrier(0);
