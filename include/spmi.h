@@ -362,6 +362,24 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
                       const float* h_in /*device [M, H]*/, int64_t M, int64_t H,
                       float* h_out /*device [M, H]*/, int x_bounded, void* stream);
 
+/* The LSTM layer step on the same loop nest: torch.nn.LSTM with seq_len 1 as driven by
+ * LSTM.forward (implicitTimeModels.py:214-230) with the two NodeMemory tables (:48-54), for
+ * ids = every node and no gate values kept.  Gates i, f, g, o; c' = f c + i g; h' = o tanh(c').
+ * Operands as two fp16 planes (the value and its residual * 2^6), the two small products of a
+ * term in an accumulator set of their own: the same three matrix instructions per term and the
+ * same accuracy as spmi_cell_f16x3_fwd, with the four gates' columns of 32 hidden units (128 KB)
+ * resident in LDS.  h_out must overlap neither h_in nor x nor c_in; c_out may be c_in (a lane
+ * reads the cell state it later writes) but no other input.  ws_ih / ws_hh from
+ * spmi_split_f16x3 of the [4H, I] / [4H, H] weights; biases nullable; I = H = 128.  Rows of x
+ * may hold any finite value; x_bounded is accepted for symmetry with spmi_gru_rows_fwd and
+ * changes nothing (the form without the magnitude pass measured slower). */
+int spmi_lstm_rows_supported(int64_t I, int64_t H);
+int spmi_lstm_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t ldx, int64_t I,
+                       const void* ws_ih, const void* ws_hh, const float* b_ih, const float* b_hh,
+                       const float* h_in /*device [M, H]*/, const float* c_in /*device [M, H]*/,
+                       int64_t M, int64_t H, float* h_out /*device [M, H]*/,
+                       float* c_out /*device [M, H]*/, int x_bounded, void* stream);
+
 /* ------------------------------------------------------------------------
  * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].
  * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites

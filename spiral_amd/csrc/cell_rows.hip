@@ -1,5 +1,5 @@
-// One GRU layer step over ALL node rows with the gate weights resident in LDS: the inference
-// form of torch.nn.GRU as driven by SequentialDecoder.forward
+// One GRU (and, further down, LSTM) layer step over ALL node rows with the gate weights
+// resident in LDS: the inference form of torch.nn.GRU as driven by SequentialDecoder.forward
 // (spiro/dtdg/models/decoder/torch/sequentialDecoder/implicitTimeModels.py:144-158) when ids
 // is every node, so that NodeMemory.get_memory / update_memory (:48-54) read one [M, H] slab
 // and write another.
@@ -341,6 +341,260 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
   store_tile(prev_row0);
 }
 
+// ---- the LSTM layer step on the same loop nest ---------------------------------------------
+// torch.nn.LSTM with seq_len 1 as driven by LSTM.forward of the reference
+// (implicitTimeModels.py:214-230) over every node: gates i, f, g, o from x W_ih^T + h W_hh^T,
+// c' = f c + i g, h' = o tanh(c').  Four gates of a 32-unit slice in three planes would take
+// 192 KB, so the operands travel as TWO planes, p0 = fp16(v) and the residual
+// p2 = fp16((v - p0) * 2^6): the main product p0(x) p0(w) goes to one accumulator set, the two
+// small products p2(x) p0(w) + p0(x) p2(w), both carrying the factor 2^6 that keeps the
+// residuals out of fp16's subnormal range, to a second set that is divided by 2^6 once at the
+// end.  Same three matrix instructions per term and the same sums as the three-plane form,
+// 128 KB of weights in LDS, eight accumulators per wave.  Rows of x of any magnitude: the
+// whole row of x is in registers when a tile starts, so a row whose largest magnitude reaches
+// 2^15 is split multiplied by the power of two that brings it to [2^13, 2^14) and its
+// accumulators are scaled back (exactly) before the first state term.  (A form without that
+// pass over the row, for callers that vouch for |x| < 2^15, measured slower, 1.22 against
+// 1.10 ms per layer at 1M rows: its K-steps wait for their rows one by one.  Not kept.)
+constexpr int kGate2 = 2 * 1024;    // one gate's planes in one K-step: [p0, residual][k half 2][32][8]
+constexpr int kStep4 = 4 * kGate2;  // i, f, g, o
+
+struct LstmRowsArgs {
+  const float* x;
+  int64_t ldx;
+  const uint4* ws_ih;  // [I/16][3][2][4H][8] fp16 (spmi_split_f16x3 of weight_ih [4H, I])
+  const uint4* ws_hh;  // [H/16][3][2][4H][8] fp16
+  const float* b_ih;
+  const float* b_hh;
+  const float* h_in;
+  const float* c_in;
+  float* h_out;
+  float* c_out;
+  int64_t M;
+  int x_bounded;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return rcpf_(1.0f + __expf(-v)); }
+
+// The twelve matrix instructions of one K-step, gate by gate, the fragments of the next gate
+// read from LDS while the current gate's instructions run (`bq`: gate i of this step on entry,
+// gate i of the step at `sb_next` on exit).
+__device__ __forceinline__ void kstep_lstm(f32x16 (&main)[4], f32x16 (&small)[4], const f16x8& p0,
+                                           const f16x8& p2, const char* sb, const char* sb_next,
+                                           f16x8 (&bq)[2]) {
+  f16x8 bn[2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const char* nx = g < 3 ? sb + (g + 1) * kGate2 : sb_next;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bn[q] = *reinterpret_cast<const f16x8*>(nx + q * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    small[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, bq[0], small[g], 0, 0, 0);
+    small[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, bq[1], small[g], 0, 0, 0);
+    main[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, bq[0], main[g], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    bq[0] = bn[0];
+    bq[1] = bn[1];
+  }
+}
+
+// One wave per SIMD: eight accumulators, the row registers and the old cell state of a tile do
+// not fit the 256 registers a wave gets when two share a SIMD.
+constexpr int kLstmWaves = 4;
+
+template <int KT>
+__global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsArgs p) {
+  constexpr int H = KT * 16;
+  constexpr int GH = 4 * H;
+  constexpr int NS = H / 32;
+  constexpr int B16 = 2 * KT * kStep4 / 16;
+  static_assert(KT % 2 == 0, "K-steps come in pairs");
+  static_assert(32 % NS == 0, "slices of one row range must fit the workgroups of one XCD");
+  extern __shared__ uint4 smem4[];
+  const char* smem = reinterpret_cast<const char*>(smem4);
+
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % NS;
+  const int group = (b & 7) + 8 * (b / (8 * NS));
+  const int n_groups = gridDim.x / NS;
+  const int j0 = slice * 32;
+
+  const int tid = threadIdx.x;
+  // LDS image [K-step: x steps, then state steps][gate][p0, residual][k half][32][8] from planes 0
+  // and 2 of the source's three, in the K order of gru_rows_kernel (64 contiguous bytes of a
+  // row per lane and K-step pair).
+  for (int c = tid; c < B16; c += kLstmWaves * 64) {
+    const int n = c & 31, lh_ = (c >> 5) & 1, q = (c >> 6) & 1, g = (c >> 7) & 3, t = c >> 9;
+    const uint4* src = t < KT ? p.ws_ih : p.ws_hh;
+    const int s_ = t < KT ? t : t - KT;
+    const int tt = (s_ & ~1) + lh_, hh = s_ & 1;
+    smem4[c] = src[((tt * 3 + 2 * q) * 2 + hh) * GH + g * H + j0 + n];
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t n_tiles = (p.M + 31) / 32;
+  const int64_t stride = static_cast<int64_t>(n_groups) * kLstmWaves;
+  int64_t tile = static_cast<int64_t>(wave) * n_groups + group;
+  if (tile >= n_tiles) return;
+
+  const int j = j0 + lr;
+  float bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    bias[g] = (p.b_ih ? p.b_ih[g * H + j] : 0.0f) + (p.b_hh ? p.b_hh[g * H + j] : 0.0f);
+
+  // Rows past M are clamped to the last row: computed, never stored.
+  auto clamp_row = [&](int64_t t) {
+    const int64_t r = t * 32 + lr;
+    return r < p.M ? r : p.M - 1;
+  };
+
+  float4 a[KT][2];
+  auto load_pair = [&](const float* src, int u) {
+    const float4* q = reinterpret_cast<const float4*>(src + 32 * u);
+    a[2 * u][0] = q[0];
+    a[2 * u][1] = q[1];
+    a[2 * u + 1][0] = q[2];
+    a[2 * u + 1][1] = q[3];
+  };
+  {
+    const float* src = p.x + clamp_row(tile) * p.ldx + 16 * lh;
+#pragma unroll
+    for (int u = 0; u < KT / 2; ++u) load_pair(src, u);
+  }
+  const char* sb = smem + lh * 512 + lr * 16;
+  f16x8 bq[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const f16x8*>(sb + q * 1024);
+  const int voff = 4 * lh * H + j;
+
+  while (tile < n_tiles) {
+    const int64_t next = tile + stride;
+    // the last iteration re-reads its own tile: valid memory, nothing is done with it
+    const float* xn = p.x + clamp_row(next < n_tiles ? next : tile) * p.ldx + 16 * lh;
+    const float* hc = p.h_in + clamp_row(tile) * H + 16 * lh;
+    const int64_t row0 = tile * 32;
+
+    f32x16 acc[4], sml[4];  // i, f, g, o: main products, small products * 2^6
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = sml[q][e] = 0.0f;
+
+    float up, down;
+    bool any_big;
+    {
+      float m = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][0].x), fabsf(a[t][0].y)), fmaxf(fabsf(a[t][0].z), fabsf(a[t][0].w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][1].x), fabsf(a[t][1].y)), fmaxf(fabsf(a[t][1].z), fabsf(a[t][1].w))));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
+      const bool big = ex >= 127 + 15 && ex != 255;                         // finite, >= 2^15
+      const int sh = big ? ex - (127 + 13) : 0;
+      up = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
+      down = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
+      any_big = __any(big);
+    }
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      f16x8 p0, p1, p2;
+      split8<true>(a[t][0], a[t][1], up, p0, p1, p2);
+      if (t & 1) load_pair(hc, t >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      kstep_lstm(acc, sml, p0, p2, sb + t * kStep4, sb + (t + 1) * kStep4, bq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (any_big) {  // rare, wave-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        // the inverse scale of row ur + 4 lh sits in lane ur + 4 lh (either half)
+        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+        const float dn = lh ? d1 : d0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[g][e] *= dn;
+          sml[g][e] *= dn;
+        }
+      }
+    }
+
+    // the old cell state of the wave's 32 x 32 output block in accumulator order (element e of
+    // lane l: row (e&3) + 8 (e>>2) + 4 (l>>5), column l&31); rows past M read the last row
+    float cy[16];
+    {
+      const float* cb = p.c_in + row0 * H;
+      const int last = static_cast<int>(p.M - 1 - row0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2) + 4 * lh;
+        cy[e] = cb[(ur < last ? ur : last) * H + j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      f16x8 p0, p1, p2;
+      split8<false>(a[t][0], a[t][1], 1.0f, p0, p1, p2);
+      if (t & 1) load_pair(xn, t >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      kstep_lstm(acc, sml, p0, p2, sb + (KT + t) * kStep4, sb + (t + 1 < KT ? KT + t + 1 : 0) * kStep4, bq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float* hb = p.h_out + row0 * H;
+    float* cb = p.c_out + row0 * H;
+    const bool whole = row0 + 32 <= p.M;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float gi = sigmoidf_(__builtin_fmaf(sml[0][e], 0x1p-6f, acc[0][e]) + bias[0]);
+      const float gf = sigmoidf_(__builtin_fmaf(sml[1][e], 0x1p-6f, acc[1][e]) + bias[1]);
+      const float gg = tanhf_(__builtin_fmaf(sml[2][e], 0x1p-6f, acc[2][e]) + bias[2]);
+      const float go = sigmoidf_(__builtin_fmaf(sml[3][e], 0x1p-6f, acc[3][e]) + bias[3]);
+      const float c = gf * cy[e] + gi * gg;
+      const float h = go * tanhf_(c);
+      const int ur = (e & 3) + 8 * (e >> 2);
+      if (whole || row0 + ur + 4 * lh < p.M) {
+        cb[ur * H + voff] = c;
+        hb[ur * H + voff] = h;
+      }
+    }
+    tile = next;
+  }
+}
+
+template <int KT>
+int launch_lstm(const LstmRowsArgs& a, hipStream_t st) {
+  constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep4;
+  static_assert(lds <= 160 * 1024, "slice image does not fit LDS");
+  auto kern = lstm_rows_kernel<KT>;
+  static bool configured = false;
+  if (!configured) {
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rows_kernel<KT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  constexpr int NS = KT / 2;
+  const int64_t n_tiles = (a.M + 31) / 32;
+  int64_t sets = (n_tiles + 8 * kLstmWaves - 1) / (8 * kLstmWaves);  // a set: 8 row groups of kLstmWaves tiles
+  const int64_t max_sets = 256 / (8 * NS);
+  if (sets > max_sets) sets = max_sets;
+  kern<<<static_cast<unsigned>(sets * 8 * NS), kLstmWaves * 64, lds, st>>>(a);
+  SPMI_CHECK_LAUNCH("lstm_rows");
+  return SPMI_OK;
+}
+
 template <int KT>
 int launch(const GruRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep;
@@ -404,6 +658,48 @@ int spmi_gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih,
   a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
   a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.h_out = h_out; a.M = M; a.x_bounded = x_bounded;
   return launch<8>(a, spmi::as_stream(stream));
+}
+
+int spmi_lstm_rows_supported(int64_t I, int64_t H) { return I == 128 && H == 128; }
+
+int spmi_lstm_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                       const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
+                       int64_t M, int64_t H, float* h_out, float* c_out, int x_bounded, void* stream) {
+  SPMI_REQUIRE(spmi_lstm_rows_supported(I, H), SPMI_ERR_UNSUPPORTED,
+               "spmi_lstm_rows_fwd: needs I = H = 128 (I=%lld H=%lld)", (long long)I, (long long)H);
+  SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: bad M=%lld",
+               (long long)M);
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(x && ws_ih && ws_hh && h_in && c_in && h_out && c_out && ldx >= I && ldx % 4 == 0,
+               SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: null pointer or bad ldx");
+  SPMI_REQUIRE(ldx < (int64_t{1} << 24), SPMI_ERR_UNSUPPORTED,
+               "spmi_lstm_rows_fwd: leading dimension %lld too large", (long long)ldx);
+  for (const void* q : {(const void*)x, ws_ih, ws_hh, (const void*)h_in, (const void*)c_in,
+                        (const void*)h_out, (const void*)c_out})
+    SPMI_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15u) == 0, SPMI_ERR_INVALID_ARG,
+                 "spmi_lstm_rows_fwd: pointers must be 16-byte aligned");
+  {
+    // h and x rows are read by several workgroups and written in column slices: the new hidden
+    // state must not land on either.  The cell state is read and written by the same lane,
+    // read first: c_out may be c_in.
+    const uintptr_t bytes = static_cast<uintptr_t>(M) * H * sizeof(float);
+    const uintptr_t xbytes = (static_cast<uintptr_t>(M - 1) * ldx + I) * sizeof(float);
+    auto apart = [](uintptr_t a0, uintptr_t an, uintptr_t b0, uintptr_t bn) { return a0 + an <= b0 || b0 + bn <= a0; };
+    const uintptr_t ho = reinterpret_cast<uintptr_t>(h_out), co = reinterpret_cast<uintptr_t>(c_out);
+    const uintptr_t hi = reinterpret_cast<uintptr_t>(h_in), ci = reinterpret_cast<uintptr_t>(c_in);
+    const uintptr_t x0 = reinterpret_cast<uintptr_t>(x);
+    SPMI_REQUIRE(apart(ho, bytes, hi, bytes) && apart(ho, bytes, x0, xbytes) && apart(ho, bytes, ci, bytes),
+                 SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: h_out overlaps an input");
+    SPMI_REQUIRE(apart(co, bytes, hi, bytes) && apart(co, bytes, x0, xbytes) && apart(co, bytes, ho, bytes) &&
+                     (co == ci || apart(co, bytes, ci, bytes)),
+                 SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: c_out overlaps an input (other than being c_in)");
+  }
+  LstmRowsArgs a{};
+  a.x = x; a.ldx = ldx;
+  a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
+  a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.c_in = c_in; a.h_out = h_out; a.c_out = c_out;
+  a.M = M; a.x_bounded = x_bounded;
+  return launch_lstm<8>(a, spmi::as_stream(stream));
 }
 
 }  // extern "C"

@@ -303,6 +303,28 @@ class LSTM(SequentialDecoder):
         return ["memory_h", "memory_c"]
 
     def _step(self, x, ids):
+        mh, mc = self.memory_h, self.memory_c
+        # Every node, nothing tracked: the kernel that keeps the gate weights in LDS (see
+        # GRU._step).  The new hidden state goes to the memory's second table; the cell state
+        # is updated in place when the step writes back, into a scratch table otherwise.
+        whole = (ids is None and x.shape[0] == mh.memory.shape[1]
+                 and all(ops.lstm_rows_ok(x if k == 0 else mh.memory[k], self._layer_params(k)[1],
+                                          *self._layer_params(k)[::2], self._layer_params(k)[3])
+                         for k in range(self.n_layers))
+                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+        if whole:
+            new_h = mh.spare() if self.training_mode else None
+            for k in range(self.n_layers):
+                h_out = new_h[k] if new_h is not None else torch.empty_like(mh.memory[k])
+                c_out = mc.memory[k] if self.training_mode else torch.empty_like(mc.memory[k])
+                # h' = sigmoid(o) * tanh(c'): bounded by 1 whatever the state holds
+                x, _c = ops.lstm_rows(x, *self._layer_params(k), mh.memory[k], mc.memory[k], h_out, c_out,
+                                      x_bounded=k > 0)
+                x = self._between_layers(x, k)
+            if new_h is not None:
+                mh.swap_spare()
+                mc._bounded = None
+            return x
         for k in range(self.n_layers):
             # h' = sigmoid(o) * tanh(c'): bounded by 1 whatever the state holds
             x, _c = ops.lstm_cell(x, *self._layer_params(k), self.memory_h.memory[k],

@@ -923,6 +923,37 @@ def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
     return h_out
 
 
+def lstm_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
+    """The whole-table LSTM kernel takes this layer (conditions as for `gru_rows_ok`)."""
+    tracked = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
+    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
+            and bool(nv.lib().spmi_lstm_rows_supported(x.shape[1], w_hh.shape[1])))
+
+
+def lstm_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, c_in: torch.Tensor,
+              h_out: torch.Tensor, c_out: torch.Tensor, x_bounded: bool = False):
+    """One LSTM layer step for every row: reads the state slabs `h_in`, `c_in` [M, H], writes
+    `h_out` (a different slab from h_in) and `c_out` (may be c_in) and returns them.  Inference
+    only (no gate values are kept)."""
+    _check_cell_args(x, h_in, None)
+    nv.require_cuda(c_in, h_out, c_out)
+    m, hd = x.shape[0], w_hh.shape[1]
+    for t in (h_in, c_in, h_out, c_out):
+        if t.shape != (m, hd) or not t.is_contiguous() or t.dtype != torch.float32 or t.device != x.device:
+            raise nv.SpmiError("lstm_rows: state slabs must be contiguous float32 [M, H] on x's device")
+    ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
+    ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().spmi_lstm_rows_fwd(
+            nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+            nv.ptr(b_hh), nv.ptr(h_in), nv.ptr(c_in), m, hd, nv.ptr(h_out), nv.ptr(c_out),
+            int(x_bounded), nv.stream()), "spmi_lstm_rows_fwd")
+    return h_out, c_out
+
+
 # GRU layers hand their gate gradients to the dense kernels as one [rows, 4H] matrix instead of
 # two [rows, 3H] ones (see GruCell._backward_packed).
 GRU_PACKED_BACKWARD = True
