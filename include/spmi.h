@@ -362,6 +362,19 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
                       const float* h_in /*device [M, H]*/, int64_t M, int64_t H,
                       float* h_out /*device [M, H]*/, int x_bounded, void* stream);
 
+/* The tanh RNN layer step on the same loop nest: torch.nn.RNN with seq_len 1 as driven by
+ * SequentialDecoder.forward (implicitTimeModels.py:144-158), ids = every node, nothing kept:
+ * h' = tanh(x W_ih^T + b_ih + h W_hh^T + b_hh).  One gate: a workgroup holds the columns of 64
+ * hidden units (96 KB, three planes), a row tile is read by H / 64 workgroups.  h_out must
+ * overlap neither h_in nor x.  ws_ih / ws_hh from spmi_split_f16x3 of the [H, I] / [H, H]
+ * weights; biases nullable; I = H = 128; rows of x may hold any finite value (x_bounded is
+ * accepted and ignored). */
+int spmi_rnn_rows_supported(int64_t I, int64_t H);
+int spmi_rnn_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t ldx, int64_t I,
+                      const void* ws_ih, const void* ws_hh, const float* b_ih, const float* b_hh,
+                      const float* h_in /*device [M, H]*/, int64_t M, int64_t H,
+                      float* h_out /*device [M, H]*/, int x_bounded, void* stream);
+
 /* The LSTM layer step on the same loop nest: torch.nn.LSTM with seq_len 1 as driven by
  * LSTM.forward (implicitTimeModels.py:214-230) with the two NodeMemory tables (:48-54), for
  * ids = every node and no gate values kept.  Gates i, f, g, o; c' = f c + i g; h' = o tanh(c').

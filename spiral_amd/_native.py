@@ -76,6 +76,9 @@ _SIGNATURES = {
     "spmi_gru_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_gru_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                   c_int, c_vp]),
+    "spmi_rnn_rows_supported": (c_int, [c_i64, c_i64]),
+    "spmi_rnn_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
+                                  c_int, c_vp]),
     "spmi_lstm_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_lstm_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
                                    c_vp, c_vp, c_int, c_vp]),

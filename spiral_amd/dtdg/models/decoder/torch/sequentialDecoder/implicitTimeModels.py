@@ -279,6 +279,22 @@ class RNN(SequentialDecoder):
         self._check_base_model()
 
     def _step(self, x, ids):
+        mem = self.memory_h
+        # every node, nothing tracked: the kernel that keeps the weights in LDS (see GRU._step)
+        whole = (ids is None and x.shape[0] == mem.memory.shape[1]
+                 and all(ops.rnn_rows_ok(x if k == 0 else mem.memory[k], self._layer_params(k)[1],
+                                         *self._layer_params(k)[::2], self._layer_params(k)[3])
+                         for k in range(self.n_layers))
+                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+        if whole:
+            new = mem.spare() if self.training_mode else None
+            for k in range(self.n_layers):
+                out = new[k] if new is not None else torch.empty_like(mem.memory[k])
+                x = ops.rnn_rows(x, *self._layer_params(k), mem.memory[k], out, x_bounded=k > 0)
+                x = self._between_layers(x, k)
+            if new is not None:
+                mem.swap_spare()
+            return x
         for k in range(self.n_layers):
             # tanh output: bounded by 1 whatever the state holds
             x = ops.rnn_cell(x, *self._layer_params(k), self.memory_h.memory[k], ids,

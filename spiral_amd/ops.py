@@ -923,6 +923,35 @@ def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
     return h_out
 
 
+def rnn_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
+    """The whole-table tanh-RNN kernel takes this layer (conditions as for `gru_rows_ok`)."""
+    tracked = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
+    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
+            and bool(nv.lib().spmi_rnn_rows_supported(x.shape[1], w_hh.shape[1])))
+
+
+def rnn_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out: torch.Tensor,
+             x_bounded: bool = False) -> torch.Tensor:
+    """One tanh-RNN layer step for every row: reads the state slab `h_in` [M, H], writes the new
+    state to `h_out` [M, H] (a different slab) and returns it.  Inference only."""
+    _check_cell_args(x, h_in, None)
+    m, hd = x.shape[0], w_hh.shape[1]
+    if h_in.shape != (m, hd) or h_out.shape != (m, hd) or not h_out.is_contiguous() \
+            or h_out.dtype != torch.float32 or h_out.device != x.device:
+        raise nv.SpmiError("rnn_rows: h_in and h_out must be contiguous float32 [M, H] slabs on x's device")
+    ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
+    ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib().spmi_rnn_rows_fwd(
+            nv.ptr(x), x.stride(0), x.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+            nv.ptr(b_hh), nv.ptr(h_in), m, hd, nv.ptr(h_out), int(x_bounded), nv.stream()),
+            "spmi_rnn_rows_fwd")
+    return h_out
+
+
 def lstm_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
     """The whole-table LSTM kernel takes this layer (conditions as for `gru_rows_ok`)."""
     tracked = torch.is_grad_enabled() and any(
