@@ -184,6 +184,49 @@ def test_whole_table_gru_step_at_full_size(big, dev):
     assert np.abs(cpu(h_a[rows]) - want).max() < 1e-5
 
 
+def test_whole_table_lstm_and_rnn_steps_at_full_size(big, dev):
+    """The LSTM and tanh-RNN forms of that kernel (spmi_lstm_rows_fwd, spmi_rnn_rows_fwd) over all
+    nodes: equal to the row-tile kernel on every row, equal to the CPU oracle on a row sample
+    that includes the first and the last tile, the old state left untouched, bit-identical when
+    launched again."""
+    if big["name"] != "config2":
+        pytest.skip("the recurrent layer does not depend on the graph: run once, at the headline size")
+    x, N, F = big["x"], big["n"], big["f"]
+    torch.manual_seed(4)
+    h0, c0 = torch.randn(N, F, device=dev), torch.randn(N, F, device=dev)
+    keep_h, keep_c = h0.clone(), c0.clone()
+    pick = np.concatenate([np.arange(40), np.arange(N - 40, N), np.random.default_rng(5).integers(0, N, 4000)])
+    rows = torch.from_numpy(pick).to(dev)
+    cpu = lambda t: t.detach().cpu().numpy()
+
+    lstm = torch.nn.LSTM(F, F, batch_first=True).to(dev)
+    p = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
+    with torch.no_grad():
+        assert ops.lstm_rows_ok(x, p[1])
+        h_a, c_a = ops.lstm_rows(x, *p, h0, c0, torch.empty_like(h0), torch.empty_like(c0))
+        h_a2, c_a2 = ops.lstm_rows(x, *p, h0, c0, torch.empty_like(h0), torch.empty_like(c0))
+        h_b, c_b = ops.lstm_cell(x, *p, h0.clone(), c0.clone(), None, mem_write=False)
+    assert torch.equal(h0, keep_h) and torch.equal(c0, keep_c)
+    assert torch.equal(h_a, h_a2) and torch.equal(c_a, c_a2)
+    assert (h_a - h_b).abs().max() < 2e-6 and (c_a - c_b).abs().max() < 8e-6
+    want_h, want_c = orc.lstm_cell(cpu(x[rows]), cpu(keep_h[rows]), cpu(keep_c[rows]), *(cpu(t) for t in p))
+    assert np.abs(cpu(h_a[rows]) - want_h).max() < 1e-5
+    assert np.abs(cpu(c_a[rows]) - want_c).max() < 1e-5 * np.abs(want_c).max()
+
+    rnn = torch.nn.RNN(F, F, batch_first=True).to(dev)
+    p = rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0
+    with torch.no_grad():
+        assert ops.rnn_rows_ok(x, p[1])
+        r_a = ops.rnn_rows(x, *p, h0, torch.empty_like(h0))
+        r_a2 = ops.rnn_rows(x, *p, h0, torch.empty_like(h0))
+        r_b = ops.rnn_cell(x, *p, h0.clone(), None, mem_write=False)
+    assert torch.equal(h0, keep_h)
+    assert torch.equal(r_a, r_a2)
+    assert (r_a - r_b).abs().max() < 2e-6
+    want = orc.rnn_cell(cpu(x[rows]), cpu(keep_h[rows]), *(cpu(t) for t in p))
+    assert np.abs(cpu(r_a[rows]) - want).max() < 1e-5
+
+
 def test_graphconv_layer_at_full_size(big, dev):
     """The whole layer as the benchmark runs it (no_grad; 128 -> 128 multiplies first,
     256 -> 512 aggregates first as DGL does for in_feats < out_feats): a sample of rows plus
