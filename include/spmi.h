@@ -364,8 +364,8 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
 
 /* The tanh RNN layer step on the same loop nest: torch.nn.RNN with seq_len 1 as driven by
  * SequentialDecoder.forward (implicitTimeModels.py:144-158), ids = every node, nothing kept:
- * h' = tanh(x W_ih^T + b_ih + h W_hh^T + b_hh).  One gate: a workgroup holds the columns of 64
- * hidden units (96 KB, three planes), a row tile is read by H / 64 workgroups.  h_out must
+ * h' = tanh(x W_ih^T + b_ih + h W_hh^T + b_hh).  One gate: as two fp16 planes (see
+ * spmi_lstm_rows_fwd) all 128 columns fit LDS, so every row is read and split once.  h_out must
  * overlap neither h_in nor x.  ws_ih / ws_hh from spmi_split_f16x3 of the [H, I] / [H, H]
  * weights; biases nullable; I = H = 128; rows of x may hold any finite value (x_bounded is
  * accepted and ignored). */

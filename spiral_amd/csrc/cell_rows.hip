@@ -402,11 +402,14 @@ __device__ __forceinline__ void kstep_lstm(f32x16 (&main)[4], f32x16 (&small)[4]
 // not fit the 256 registers a wave gets when two share a SIMD.
 constexpr int kLstmWaves = 4;
 
-template <int KT>
+// RNN: the four column tiles are the four 32-unit blocks of ONE gate (the tanh RNN, H = 128):
+// the workgroup holds every column, rows are read once.
+template <int KT, bool RNN>
 __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsArgs p) {
   constexpr int H = KT * 16;
-  constexpr int GH = 4 * H;
-  constexpr int NS = H / 32;
+  constexpr int GH = RNN ? H : 4 * H;
+  constexpr int NS = RNN ? 1 : H / 32;
+  static_assert(!RNN || H == 128, "four column tiles");
   constexpr int B16 = 2 * KT * kStep4 / 16;
   static_assert(KT % 2 == 0, "K-steps come in pairs");
   static_assert(32 % NS == 0, "slices of one row range must fit the workgroups of one XCD");
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsA
     const uint4* src = t < KT ? p.ws_ih : p.ws_hh;
     const int s_ = t < KT ? t : t - KT;
     const int tt = (s_ & ~1) + lh_, hh = s_ & 1;
-    smem4[c] = src[((tt * 3 + 2 * q) * 2 + hh) * GH + g * H + j0 + n];
+    smem4[c] = src[((tt * 3 + 2 * q) * 2 + hh) * GH + (RNN ? g * 32 : g * H + j0) + n];
   }
   __syncthreads();
 
@@ -444,8 +447,10 @@ __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsA
   const int j = j0 + lr;
   float bias[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    bias[g] = (p.b_ih ? p.b_ih[g * H + j] : 0.0f) + (p.b_hh ? p.b_hh[g * H + j] : 0.0f);
+  for (int g = 0; g < 4; ++g) {
+    const int col = RNN ? g * 32 + lr : g * H + j;
+    bias[g] = (p.b_ih ? p.b_ih[col] : 0.0f) + (p.b_hh ? p.b_hh[col] : 0.0f);
+  }
 
   // Rows past M are clamped to the last row: computed, never stored.
   auto clamp_row = [&](int64_t t) {
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsA
     // the old cell state of the wave's 32 x 32 output block in accumulator order (element e of
     // lane l: row (e&3) + 8 (e>>2) + 4 (l>>5), column l&31); rows past M read the last row
     float cy[16];
-    {
+    if constexpr (!RNN) {
       const float* cb = p.c_in + row0 * H;
       const int last = static_cast<int>(p.M - 1 - row0);
 #pragma unroll
@@ -554,20 +559,32 @@ __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsA
     }
 
     float* hb = p.h_out + row0 * H;
-    float* cb = p.c_out + row0 * H;
     const bool whole = row0 + 32 <= p.M;
+    if constexpr (RNN) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float gi = sigmoidf_(__builtin_fmaf(sml[0][e], 0x1p-6f, acc[0][e]) + bias[0]);
-      const float gf = sigmoidf_(__builtin_fmaf(sml[1][e], 0x1p-6f, acc[1][e]) + bias[1]);
-      const float gg = tanhf_(__builtin_fmaf(sml[2][e], 0x1p-6f, acc[2][e]) + bias[2]);
-      const float go = sigmoidf_(__builtin_fmaf(sml[3][e], 0x1p-6f, acc[3][e]) + bias[3]);
-      const float c = gf * cy[e] + gi * gg;
-      const float h = go * tanhf_(c);
-      const int ur = (e & 3) + 8 * (e >> 2);
-      if (whole || row0 + ur + 4 * lh < p.M) {
-        cb[ur * H + voff] = c;
-        hb[ur * H + voff] = h;
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        if (whole || row0 + ur + 4 * lh < p.M) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            hb[ur * H + 4 * lh * H + g * 32 + lr] = tanhf_(__builtin_fmaf(sml[g][e], 0x1p-6f, acc[g][e]) + bias[g]);
+        }
+      }
+    } else {
+      float* cb = p.c_out + row0 * H;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float gi = sigmoidf_(__builtin_fmaf(sml[0][e], 0x1p-6f, acc[0][e]) + bias[0]);
+        const float gf = sigmoidf_(__builtin_fmaf(sml[1][e], 0x1p-6f, acc[1][e]) + bias[1]);
+        const float gg = tanhf_(__builtin_fmaf(sml[2][e], 0x1p-6f, acc[2][e]) + bias[2]);
+        const float go = sigmoidf_(__builtin_fmaf(sml[3][e], 0x1p-6f, acc[3][e]) + bias[3]);
+        const float c = gf * cy[e] + gi * gg;
+        const float h = go * tanhf_(c);
+        const int ur = (e & 3) + 8 * (e >> 2);
+        if (whole || row0 + ur + 4 * lh < p.M) {
+          cb[ur * H + voff] = c;
+          hb[ur * H + voff] = h;
+        }
       }
     }
     tile = next;
@@ -578,10 +595,10 @@ template <int KT>
 int launch_lstm(const LstmRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep4;
   static_assert(lds <= 160 * 1024, "slice image does not fit LDS");
-  auto kern = lstm_rows_kernel<KT>;
+  auto kern = lstm_rows_kernel<KT, false>;
   static bool configured = false;
   if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rows_kernel<KT>),
+    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rows_kernel<KT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
@@ -595,187 +612,32 @@ int launch_lstm(const LstmRowsArgs& a, hipStream_t st) {
   return SPMI_OK;
 }
 
-// ---- the tanh RNN layer step on the same loop nest -------------------------------------------
+// ---- the tanh RNN layer step --------------------------------------------------------------
 // torch.nn.RNN (tanh) with seq_len 1 as driven by SequentialDecoder.forward
 // (implicitTimeModels.py:144-158) over every node: h' = tanh(x W_ih^T + b_ih + h W_hh^T + b_hh).
-// One gate, so a workgroup holds the columns of 64 hidden units (three planes, 96 KB) and a
-// row tile is read by H / 64 workgroups; every split of eight row values feeds six matrix
-// instructions.  Rows of x of any magnitude as in lstm_rows_kernel (magnitudes taken up front
-// from the row registers).
-constexpr int kStepR = 2 * kGate;  // two column tiles of 32 units, three planes each
-
-template <int KT>
-__global__ __launch_bounds__(512, 1) void rnn_rows_kernel(GruRowsArgs p) {
-  constexpr int H = KT * 16;
-  constexpr int NS = H / 64;  // column slices
-  constexpr int B16 = 2 * KT * kStepR / 16;
-  static_assert(KT % 4 == 0, "64-unit slices and K-step pairs");
-  extern __shared__ uint4 smem4[];
-  const char* smem = reinterpret_cast<const char*>(smem4);
-
-  const int b = blockIdx.x;
-  const int slice = (b >> 3) % NS;
-  const int group = (b & 7) + 8 * (b / (8 * NS));
-  const int n_groups = gridDim.x / NS;
-  const int j0 = slice * 64;
-
-  const int tid = threadIdx.x;
-  // LDS image [K-step: x steps, then state steps][column tile][plane][k half][32][8], K order as
-  // in gru_rows_kernel; the source planes are [K-step][plane][k half][H][8]
-  for (int c = tid; c < B16; c += 512) {
-    const int n = c & 31, lh_ = (c >> 5) & 1, q = (c >> 6) % 3, nb = (c / 192) & 1, t = c / 384;
-    const uint4* src = t < KT ? p.ws_ih : p.ws_hh;
-    const int s_ = t < KT ? t : t - KT;
-    const int tt = (s_ & ~1) + lh_, hh = s_ & 1;
-    smem4[c] = src[((tt * 3 + q) * 2 + hh) * H + j0 + nb * 32 + n];
-  }
-  __syncthreads();
-
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31;
-  const int lh = lane >> 5;
-  const int64_t n_tiles = (p.M + 31) / 32;
-  const int64_t stride = static_cast<int64_t>(n_groups) * 8;
-  int64_t tile = static_cast<int64_t>(wave) * n_groups + group;
-  if (tile >= n_tiles) return;
-
-  float bias[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int j = j0 + nb * 32 + lr;
-    bias[nb] = (p.b_ih ? p.b_ih[j] : 0.0f) + (p.b_hh ? p.b_hh[j] : 0.0f);
-  }
-
-  // Rows past M are clamped to the last row: computed, never stored.
-  auto clamp_row = [&](int64_t t) {
-    const int64_t r = t * 32 + lr;
-    return r < p.M ? r : p.M - 1;
-  };
-
-  float4 a[KT][2];
-  auto load_pair = [&](const float* src, int u) {
-    const float4* q = reinterpret_cast<const float4*>(src + 32 * u);
-    a[2 * u][0] = q[0];
-    a[2 * u][1] = q[1];
-    a[2 * u + 1][0] = q[2];
-    a[2 * u + 1][1] = q[3];
-  };
-  {
-    const float* src = p.x + clamp_row(tile) * p.ldx + 16 * lh;
-#pragma unroll
-    for (int u = 0; u < KT / 2; ++u) load_pair(src, u);
-  }
-  const char* sb = smem + lh * 512 + lr * 16;
-  const int voff = 4 * lh * H + j0 + lr;
-
-  auto kstep = [&](f32x16 (&acc)[2], const f16x8& p0, const f16x8& p1, const f16x8& p2, const char* sf) {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const f16x8 w0 = *reinterpret_cast<const f16x8*>(sf + nb * kGate);
-      const f16x8 w1 = *reinterpret_cast<const f16x8*>(sf + nb * kGate + 1024);
-      const f16x8 w2 = *reinterpret_cast<const f16x8*>(sf + nb * kGate + 2048);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, w1, acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, w2, acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, w0, acc[nb], 0, 0, 0);
-    }
-  };
-
-  while (tile < n_tiles) {
-    const int64_t next = tile + stride;
-    // the last iteration re-reads its own tile: valid memory, nothing is done with it
-    const float* xn = p.x + clamp_row(next < n_tiles ? next : tile) * p.ldx + 16 * lh;
-    const float* hc = p.h_in + clamp_row(tile) * H + 16 * lh;
-    const int64_t row0 = tile * 32;
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
-
-    float up, down;
-    bool any_big;
-    {
-      float m = 0.0f;
-#pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][0].x), fabsf(a[t][0].y)), fmaxf(fabsf(a[t][0].z), fabsf(a[t][0].w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a[t][1].x), fabsf(a[t][1].y)), fmaxf(fabsf(a[t][1].z), fabsf(a[t][1].w))));
-      }
-      m = fmaxf(m, __shfl_xor(m, 32));
-      const int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);  // biased exponent
-      const bool big = ex >= 127 + 15 && ex != 255;                         // finite, >= 2^15
-      const int sh = big ? ex - (127 + 13) : 0;
-      up = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
-      down = __uint_as_float(static_cast<uint32_t>(127 + sh) << 23);
-      any_big = __any(big);
-    }
-
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      f16x8 p0, p1, p2;
-      split8<true>(a[t][0], a[t][1], up, p0, p1, p2);
-      if (t & 1) load_pair(hc, t >> 1);
-      __builtin_amdgcn_sched_barrier(0);
-      kstep(acc, p0, p1, p2, sb + t * kStepR);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    if (any_big) {  // rare, wave-uniform
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ur = (e & 3) + 8 * (e >> 2);
-        // the inverse scale of row ur + 4 lh sits in lane ur + 4 lh (either half)
-        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
-        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
-        const float dn = lh ? d1 : d0;
-        acc[0][e] *= dn;
-        acc[1][e] *= dn;
-      }
-    }
-
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      f16x8 p0, p1, p2;
-      split8<false>(a[t][0], a[t][1], 1.0f, p0, p1, p2);
-      if (t & 1) load_pair(xn, t >> 1);
-      __builtin_amdgcn_sched_barrier(0);
-      kstep(acc, p0, p1, p2, sb + (KT + t) * kStepR);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    float* ob = p.h_out + row0 * H;
-    const bool whole = row0 + 32 <= p.M;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ur = (e & 3) + 8 * (e >> 2);
-      if (whole || row0 + ur + 4 * lh < p.M) {
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) ob[ur * H + voff + nb * 32] = tanhf_(acc[nb][e] + bias[nb]);
-      }
-    }
-    tile = next;
-  }
-}
-
+// One gate: in two planes all 128 columns fit LDS (128 KB), so the step runs on
+// lstm_rows_kernel<KT, true> with the four 32-unit blocks of the gate in place of four gates:
+// every row is read once and split once (0.33 ms per layer at 1M rows; a three-plane form with
+// 64 columns per workgroup and two waves per SIMD, which reads the rows twice, took 0.38).
 template <int KT>
 int launch_rnn(const GruRowsArgs& a, hipStream_t st) {
-  constexpr size_t lds = static_cast<size_t>(2 * KT) * kStepR;
-  static_assert(lds <= 160 * 1024, "slice image does not fit LDS");
-  auto kern = rnn_rows_kernel<KT>;
+  constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep4;
+  static_assert(lds <= 160 * 1024, "weight image does not fit LDS");
+  LstmRowsArgs l{};
+  l.x = a.x; l.ldx = a.ldx; l.ws_ih = a.ws_ih; l.ws_hh = a.ws_hh; l.b_ih = a.b_ih; l.b_hh = a.b_hh;
+  l.h_in = a.h_in; l.h_out = a.h_out; l.M = a.M;
+  auto kern = lstm_rows_kernel<KT, true>;
   static bool configured = false;
   if (!configured) {
     SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  constexpr int NS = KT / 4;
   const int64_t n_tiles = (a.M + 31) / 32;
-  int64_t sets = (n_tiles + 63) / 64;  // a row group's workgroup has 8 waves, a set 8 groups
-  const int64_t max_sets = 256 / (8 * NS);
-  if (sets > max_sets) sets = max_sets;
-  kern<<<static_cast<unsigned>(sets * 8 * NS), 512, lds, st>>>(a);
+  int64_t wgs = (n_tiles + kLstmWaves - 1) / kLstmWaves;  // kLstmWaves tiles in flight per workgroup
+  wgs = (wgs + 7) / 8 * 8;                                // whole sets of 8 XCDs
+  if (wgs > 256) wgs = 256;
+  kern<<<static_cast<unsigned>(wgs), kLstmWaves * 64, lds, st>>>(l);
   SPMI_CHECK_LAUNCH("rnn_rows");
   return SPMI_OK;
 }

@@ -1,5 +1,5 @@
-"""The whole-table tanh-RNN layer step (spmi_rnn_rows_fwd, csrc/cell_rows.hip): the weight
-columns of 64 hidden units resident in LDS, rows streamed past them, new state written to a
+"""The whole-table tanh-RNN layer step (spmi_rnn_rows_fwd, csrc/cell_rows.hip): the whole
+weight matrix resident in LDS as two fp16 planes, rows streamed past it, new state written to a
 second slab.  Checked against the CPU oracle (1e-5 relative to the largest entry of the expected
 state), against spmi_cell_f16x3_fwd, which sums the same products in another order, and through
 the decoder, whose node memory trades tables."""
