@@ -277,6 +277,31 @@ def sageconv_gcn_torch(src, dst, n, x, weight, bias, act=None, slope=0.01):
     return rst
 
 
+def sageconv_mean_torch(src, dst, n, x, w_self, w_neigh, bias, act=None, slope=0.01):
+    """DGL 0.8 SAGEConv.forward, aggregator 'mean', in differentiable torch ops:
+    h_neigh = mean of the in-neighbours (0 without in-edges); fc_neigh (no bias of its own) runs
+    first iff in > out; rst = fc_self(x) + h_neigh + bias, activation."""
+    import torch
+
+    src_t = torch.as_tensor(np.asarray(src), dtype=torch.long)
+    dst_t = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+    before = x.shape[1] > w_neigh.shape[0]
+    h = x @ w_neigh.t() if before else x
+    neigh = torch.zeros(n, h.shape[1], dtype=h.dtype).index_add_(0, dst_t, h[src_t])
+    degs = torch.bincount(dst_t, minlength=n).to(h.dtype).clamp(min=1)
+    h_neigh = neigh / degs[:, None]
+    if not before:
+        h_neigh = h_neigh @ w_neigh.t()
+    rst = x @ w_self.t() + h_neigh
+    if bias is not None:
+        rst = rst + bias
+    if act == "relu":
+        rst = torch.relu(rst)
+    elif act == "leaky_relu":
+        rst = torch.nn.functional.leaky_relu(rst, slope)
+    return rst
+
+
 def gatconv_torch(src, dst, n, x, fc_weight, attn_l, attn_r, bias, heads, negative_slope=0.2,
                   act=None, slope=0.01, res_weight=None, residual=False):
     """DGL 0.8 GATConv.forward in differentiable torch index ops (GATConv is the layer the

@@ -1,7 +1,7 @@
 """Static graph encoders applied to one snapshot at a time; API of
 spiro/dtdg/models/encoder/implicitTimeEncoder/staticGraphEncoder.py:35-117.
 
-GCN is the encoder on the accelerated path; SGCN, GraphSage ('gcn' aggregator) and GAT sit
+GCN is the encoder on the accelerated path; SGCN, GraphSage ('gcn' and 'mean' aggregators) and GAT sit
 on the same aggregation kernel (GAT adds the edge-softmax kernels).
 """
 from abc import abstractmethod

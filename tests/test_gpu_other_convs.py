@@ -1,4 +1,4 @@
-"""SGConv and SAGEConv('gcn') on the GPU against torch restatements of DGL 0.8's layers
+"""SGConv and SAGEConv('gcn', 'mean') on the GPU against torch restatements of DGL 0.8's layers
 (parity unpinned by the reference: DGL is absent and it holds no fixture).  fp32, 1e-5
 relative to the largest magnitude for outputs and gradients."""
 import numpy as np
@@ -74,9 +74,37 @@ def test_sageconv_gcn(dev, fi, fo, act):
     assert rel(conv.fc_neigh.weight.grad.cpu(), w.grad) < 1e-5
     assert rel(conv.bias.grad.cpu(), b.grad) < 1e-5
     with pytest.raises(NotImplementedError):
-        SAGEConv(fi, fo, "mean")
+        SAGEConv(fi, fo, "pool")
     with pytest.raises(GraphError):
         SAGEConv(fi, fo, "sum")
+
+
+@pytest.mark.parametrize("fi,fo,act", [(16, 8, "leaky_relu"), (16, 16, None), (12, 32, "relu")])
+def test_sageconv_mean(dev, fi, fo, act):
+    """'mean' aggregator: own features and the mean of the in-neighbours through two maps
+    (nodes without in-edges get a zero mean), forward and every gradient."""
+    n = 800
+    src, dst, g = _graph(dev, n, seed=3 * fi + fo)
+    torch.manual_seed(fo)
+    fn = {"leaky_relu": F.leaky_relu, "relu": F.relu, None: None}[act]
+    conv = SAGEConv(fi, fo, "mean", activation=fn).to(dev)
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, fi)
+    xr = x.clone().requires_grad_()
+    ws = conv.fc_self.weight.detach().cpu().clone().requires_grad_()
+    wn = conv.fc_neigh.weight.detach().cpu().clone().requires_grad_()
+    b = conv.bias.detach().cpu().clone().requires_grad_()
+    y_ref = orc.sageconv_mean_torch(src, dst, n, xr, ws, wn, b, act)
+    y_ref.pow(2).sum().backward()
+    xg = x.to(dev).requires_grad_()
+    y = conv(g, xg)
+    y.pow(2).sum().backward()
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert rel(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel(conv.fc_self.weight.grad.cpu(), ws.grad) < 1e-5
+    assert rel(conv.fc_neigh.weight.grad.cpu(), wn.grad) < 1e-5
+    assert rel(conv.bias.grad.cpu(), b.grad) < 1e-5
 
 
 def test_encoders_run(dev):
@@ -88,4 +116,6 @@ def test_encoders_run(dev):
     h, out_ids = SGCN(2, 12, 16, allow_zero_in_degree=True).to(dev)((snap, ids))
     assert h.shape == (n, 16) and out_ids is ids
     h, _ = GraphSage("gcn", 12, 16, depth=3, activation=F.leaky_relu).to(dev)((snap, ids))
+    assert h.shape == (n, 16) and torch.isfinite(h).all()
+    h, _ = GraphSage("mean", 12, 16, depth=2, activation=F.leaky_relu).to(dev)((snap, ids))
     assert h.shape == (n, 16) and torch.isfinite(h).all()
