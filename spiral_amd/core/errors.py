@@ -14,3 +14,8 @@ class GraphError(Exception):
 
 
 DGLError = GraphError
+
+
+class BackendNotSupportedError(Exception):
+    """A backend other than PyTorch was asked for (spiro/core/errors.py; the TensorFlow
+    backend of the reference is not part of this library)."""

@@ -1,0 +1,22 @@
+"""The import lines of the reference's pipeline (examples/torch/citation_prediction.py:7-14) with
+the package name swapped resolve to the classes on the path."""
+import pytest
+
+
+def test_reference_pipeline_imports():
+    from spiral_amd.core.backends import PYTORCH, TENSORFLOW
+    from spiral_amd.core.config import get_backend, set_backend
+    from spiral_amd.core.errors import BackendNotSupportedError
+
+    set_backend(PYTORCH)
+    assert get_backend() == PYTORCH
+    with pytest.raises(BackendNotSupportedError):
+        set_backend(TENSORFLOW)
+    from spiral_amd.automl.model_assembler import assembler
+    from spiral_amd.dtdg.models.decoder.sequentialDecoders import GRU, LSTM, RNN
+    from spiral_amd.dtdg.models.decoder.simpleDecoders import MLP
+    from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder import implicitTimeModels as itm
+    from spiral_amd.dtdg.models.encoder.implicitTimeEncoder.staticGraphEncoder import GAT, GCN, SGCN, GraphSage
+
+    assert (GRU, LSTM, RNN) == (itm.GRU, itm.LSTM, itm.RNN)
+    assert all(callable(c) for c in (assembler, MLP, GCN, GAT, SGCN, GraphSage))
