@@ -29,6 +29,8 @@
 //    (blockIdx -> XCD is round-robin) and walk the same tiles, so the rows they all read
 //    come from HBM once and from that XCD's L2 afterwards.
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -51,15 +53,22 @@ struct RowsArgs {
   int slices;   // n_total / (NB * 32)
 };
 
-__device__ __forceinline__ void split8(const float4& lo, const float4& hi, f16x8& p0, f16x8& p1,
+// The three planes of eight consecutive k of one row, the row's power-of-two scale applied on
+// the way.  p1 is taken from p0 by a packed fp16 multiply (equal to fp16(v / 64) wherever
+// p0 / 64 is a normal fp16 number; below that, one more rounding of at most 2^-25) and the
+// residual v - p0 by a mixed-precision fma that reads the fp16 value directly.
+__device__ __forceinline__ void split8(const float4& lo, const float4& hi, float m, f16x8& p0, f16x8& p1,
                                        f16x8& p2) {
-  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] *= m;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) p0[q] = static_cast<_Float16>(v[q]);
+  p1 = p0 * static_cast<_Float16>(0x1p-6f);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const _Float16 h = static_cast<_Float16>(v[q]);
-    p0[q] = h;
-    p1[q] = static_cast<_Float16>(v[q] * 0x1p-6f);
-    p2[q] = static_cast<_Float16>((v[q] - static_cast<float>(h)) * 0x1p6f);
+    const float d = __builtin_fmaf(static_cast<float>(p0[q]), -1.0f, v[q]);
+    p2[q] = static_cast<_Float16>(d * 0x1p6f);
   }
 }
 
@@ -175,12 +184,7 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       f16x8 p0, p1, p2;
-      {
-        float4 lo = a[t][0], hi = a[t][1];
-        lo.x *= up; lo.y *= up; lo.z *= up; lo.w *= up;
-        hi.x *= up; hi.y *= up; hi.z *= up; hi.w *= up;
-        split8(lo, hi, p0, p1, p2);
-      }
+      split8(a[t][0], a[t][1], up, p0, p1, p2);
       if (t & 1) load_pair(src, t >> 1);
       // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
       // the tile and then needs a second copy of the whole row in registers.
@@ -203,23 +207,39 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
     const int64_t row0 = tile * 32;
     float* obase = p.out + row0 * p.ldo + col0;  // wave-uniform
     const int voff = 4 * lh * static_cast<int>(p.ldo) + lr;
+    // One decision per tile, not per element: the activation and whether every row of the tile
+    // exists are wave-uniform, and asked inside the loops they cost a scalar branch or two for
+    // each of the 16 NB results of a lane.
+    auto finish = [&](auto act_tag, auto whole_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      constexpr bool WHOLE = decltype(whole_tag)::value;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ur = (e & 3) + 8 * (e >> 2);
-      if (row0 + ur + 4 * lh >= p.M) continue;
-      float* o = obase + ur * p.ldo;
-      // the inverse scale of output row ur + 4 lh sits in lane ur + 4 lh (either half)
-      const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
-      const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
-      const float dn = lh ? d1 : d0;
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        if constexpr (!WHOLE) {
+          if (row0 + ur + 4 * lh >= p.M) continue;
+        }
+        float* o = obase + ur * p.ldo;
+        // the inverse scale of output row ur + 4 lh sits in lane ur + 4 lh (either half)
+        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+        const float dn = lh ? d1 : d0;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        float v = acc[nb][e] * dn + bias[nb];
-        if (p.act == 1) v = fmaxf(v, 0.0f);
-        else if (p.act == 2) v = v > 0.0f ? v : v * p.slope;
-        o[voff + nb * 32] = v * rs[e];
+        for (int nb = 0; nb < NB; ++nb) {
+          float v = acc[nb][e] * dn + bias[nb];
+          if constexpr (ACT == 1) v = fmaxf(v, 0.0f);
+          else if constexpr (ACT == 2) v = v > 0.0f ? v : v * p.slope;
+          o[voff + nb * 32] = v * rs[e];
+        }
       }
-    }
+    };
+    auto finish_act = [&](auto whole_tag) {
+      if (p.act == 0) finish(std::integral_constant<int, 0>{}, whole_tag);
+      else if (p.act == 1) finish(std::integral_constant<int, 1>{}, whole_tag);
+      else finish(std::integral_constant<int, 2>{}, whole_tag);
+    };
+    if (row0 + 32 <= p.M) finish_act(std::true_type{});
+    else finish_act(std::false_type{});
     tile = next;
   }
 }
