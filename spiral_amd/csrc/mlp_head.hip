@@ -212,14 +212,17 @@ __device__ __forceinline__ void split_planes(float v, _Float16& p0, _Float16& p1
   p2 = static_cast<_Float16>((v - static_cast<float>(p0)) * 0x1p6f);
 }
 
+// Eight values at once: p1 from p0 by a packed fp16 multiply (equal to fp16(v / 64) wherever
+// p0 / 64 is a normal fp16 number; below that, one more rounding of at most 2^-25), the
+// residual by a mixed-precision fma that reads the fp16 value directly.
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& x0, f16x8& x1, f16x8& x2) {
 #pragma unroll
+  for (int q = 0; q < 8; ++q) x0[q] = static_cast<_Float16>(v[q]);
+  x1 = x0 * static_cast<_Float16>(0x1p-6f);
+#pragma unroll
   for (int q = 0; q < 8; ++q) {
-    _Float16 q0, q1, q2;
-    split_planes(v[q], q0, q1, q2);
-    x0[q] = q0;
-    x1[q] = q1;
-    x2[q] = q2;
+    const float d = __builtin_fmaf(static_cast<float>(x0[q]), -1.0f, v[q]);
+    x2[q] = static_cast<_Float16>(d * 0x1p6f);
   }
 }
 
@@ -235,6 +238,7 @@ __device__ __forceinline__ f32x16 mfma3(const char* img, const f16x8& x0, const 
 
 template <int KT>
 __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpArgs p) {
+  static_assert(KT % 2 == 0, "rows are read in pairs of K-steps");
   extern __shared__ float4 smem4[];
   char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT][3][2][32][8] fp16
   char* s_tail = s_l1 + KT * kKStep;                       // [n_rest][2][3][2][32][8] fp16
@@ -251,7 +255,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
     const float v = f < p.o1p ? p.w1t[k * p.o1p + f] : 0.0f;
     _Float16 q0, q1, q2;
     split_planes(v, q0, q1, q2);
-    _Float16* dst = reinterpret_cast<_Float16*>(s_l1 + (k >> 4) * kKStep + ((k >> 3) & 1) * 512 + f * 16) + (k & 7);
+    // a lane half reads 64 contiguous bytes of its row per pair of K-steps: inputs
+    // 32 u + 16 half + 8 s + {0..7} sit in K-step 2 u + s, k half `half`
+    const int step = 2 * (k >> 5) + ((k >> 3) & 1), half = (k >> 4) & 1;
+    _Float16* dst = reinterpret_cast<_Float16*>(s_l1 + step * kKStep + half * 512 + f * 16) + (k & 7);
     dst[0] = q0;
     dst[kPlane / 2] = q1;
     dst[kPlane] = q2;
@@ -297,11 +304,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
   {
     int64_t r = tile * 32 + lr;
     r = r < p.M ? r : p.M - 1;  // clamp: computed, never stored
-    const float* src = p.x + r * p.ldx + 8 * lh;
+    const float* src = p.x + r * p.ldx + 16 * lh;
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
-      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+      a[t][0] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1));
+      a[t][1] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1) + 4);
     }
   }
   const int frag = lh * 512 + lr * 16;  // this lane's 16 bytes inside a plane [k half][unit][8]
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
     const int64_t next = tile + stride;
     int64_t r = (next < n_tiles ? next : tile) * 32 + lr;  // last pass re-reads its own tile
     r = r < p.M ? r : p.M - 1;
-    const float* src = p.x + r * p.ldx + 8 * lh;
+    const float* src = p.x + r * p.ldx + 16 * lh;
 
     f32x16 cur;
 #pragma unroll
@@ -321,8 +328,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
                           a[t][1].x, a[t][1].y, a[t][1].z, a[t][1].w};
       f16x8 x0, x1, x2;
       split8(v, x0, x1, x2);
-      a[t][0] = *reinterpret_cast<const float4*>(src + 16 * t);
-      a[t][1] = *reinterpret_cast<const float4*>(src + 16 * t + 4);
+      a[t][0] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1));
+      a[t][1] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1) + 4);
       __builtin_amdgcn_sched_barrier(0);  // keeps the reloads from being hoisted over the tile
       cur = mfma3(s_l1 + t * kKStep + frag, x0, x1, x2, cur);
       __builtin_amdgcn_sched_barrier(0);
@@ -367,9 +374,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
     const int64_t row = tile * 32 + lr;
     if (row < p.M) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int f = (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (f < out_last) p.out[row * p.ldo + f] = final_activation(cur[e], p.final_act);
+      for (int q = 0; q < 4; ++q) {
+        if (8 * q >= out_last) break;  // uniform: a one-unit output tests four elements, not 16
+#pragma unroll
+        for (int e = 4 * q; e < 4 * q + 4; ++e) {
+          const int f = (e & 3) + 8 * q + 4 * lh;
+          if (f < out_last) p.out[row * p.ldo + f] = final_activation(cur[e], p.final_act);
+        }
       }
     }
     tile = next;
