@@ -351,12 +351,7 @@ int launch_config(const FusedArgs& a, hipStream_t st) {
   constexpr size_t lds = 2 * sizeof(float) * (kRows * (BK + 1) + BK * NC);
   static_assert(lds <= 160 * 1024, "LDS stage does not fit");
   auto kernel = fused_cell_kernel<CELL, JSUB, WC, BK>;
-  static bool configured = false;  // raising the dynamic-LDS limit is needed once per kernel
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(kernel, lds);
   const unsigned grid = static_cast<unsigned>((a.M + kRows - 1) / kRows);
   kernel<<<grid, 256 * WC, lds, st>>>(a);
   SPMI_CHECK_LAUNCH("fused_cell");

@@ -596,12 +596,7 @@ int launch_lstm(const LstmRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep4;
   static_assert(lds <= 160 * 1024, "slice image does not fit LDS");
   auto kern = lstm_rows_kernel<KT, false>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rows_kernel<KT, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(kern, lds);
   constexpr int NS = KT / 2;
   const int64_t n_tiles = (a.M + 31) / 32;
   int64_t sets = (n_tiles + 8 * kLstmWaves - 1) / (8 * kLstmWaves);  // a set: 8 row groups of kLstmWaves tiles
@@ -627,12 +622,7 @@ int launch_rnn(const GruRowsArgs& a, hipStream_t st) {
   l.x = a.x; l.ldx = a.ldx; l.ws_ih = a.ws_ih; l.ws_hh = a.ws_hh; l.b_ih = a.b_ih; l.b_hh = a.b_hh;
   l.h_in = a.h_in; l.h_out = a.h_out; l.M = a.M;
   auto kern = lstm_rows_kernel<KT, true>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(kern, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
   int64_t wgs = (n_tiles + kLstmWaves - 1) / kLstmWaves;  // kLstmWaves tiles in flight per workgroup
   wgs = (wgs + 7) / 8 * 8;                                // whole sets of 8 XCDs
@@ -647,14 +637,8 @@ int launch(const GruRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep;
   static_assert(lds <= 160 * 1024, "weight slice does not fit LDS");
   auto kern = a.x_bounded ? gru_rows_kernel<KT, true> : gru_rows_kernel<KT, false>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rows_kernel<KT, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_rows_kernel<KT, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, true>), lds);  // each use keeps its own record
+  SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, false>), lds);
   // One workgroup per CU (the slice image takes most of its LDS); a small batch gets as many
   // row groups as it has tiles for, in whole sets of 8 XCDs x NS slices.
   constexpr int NS = KT / 2;

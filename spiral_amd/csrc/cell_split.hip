@@ -799,14 +799,8 @@ int launch_config(const SplitArgs& a, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS stage does not fit");
   auto plain = split_cell_kernel<MODE, CELL, JSUB, WC, false, PIPE>;
   auto gathered = split_cell_kernel<MODE, CELL, JSUB, WC, true, PIPE>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(plain),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gathered),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(plain, lds);
+  SPMI_RAISE_LDS_LIMIT(gathered, lds);
   const unsigned grid = static_cast<unsigned>((a.M + kRows - 1) / kRows);
   if (a.ids) gathered<<<grid, 256 * WC, lds, st>>>(a);
   else plain<<<grid, 256 * WC, lds, st>>>(a);

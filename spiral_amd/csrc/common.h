@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -48,4 +49,35 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
     hipError_t e_ = (expr);                                                            \
     if (e_ != hipSuccess)                                                              \
       return ::spmi::fail(SPMI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace spmi {
+
+// A kernel's dynamic-LDS limit is a property of the kernel ON ONE DEVICE: a process that
+// drives several GPUs has to raise it on each.  One LdsLimit per kernel (a function-local
+// static at the launch site) remembers what has been set where.
+constexpr int kLdsLimitDevices = 64;
+struct LdsLimit {
+  std::atomic<size_t> bytes[kLdsLimitDevices] = {};
+};
+
+inline int raise_lds_limit(const void* kernel, size_t bytes, LdsLimit& seen) {
+  int dev = 0;
+  SPMI_CHECK_HIP(hipGetDevice(&dev));
+  SPMI_REQUIRE(dev >= 0 && dev < kLdsLimitDevices, SPMI_ERR_UNSUPPORTED,
+               "device ordinal %d beyond %d", dev, kLdsLimitDevices);
+  if (seen.bytes[dev].load(std::memory_order_acquire) >= bytes) return SPMI_OK;
+  SPMI_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(bytes)));
+  seen.bytes[dev].store(bytes, std::memory_order_release);
+  return SPMI_OK;
+}
+
+}  // namespace spmi
+
+#define SPMI_RAISE_LDS_LIMIT(kernel, bytes)                                              \
+  do {                                                                                   \
+    static ::spmi::LdsLimit seen_;                                                       \
+    if (int rc_ = ::spmi::raise_lds_limit(reinterpret_cast<const void*>(kernel), (bytes), seen_)) \
+      return rc_;                                                                        \
   } while (0)

@@ -249,12 +249,7 @@ int launch(const RowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(KT) * 3 * NB * 32 * 32;
   static_assert(lds <= 160 * 1024, "weight image does not fit LDS");
   auto kern = gemm_rows_kernel<KT, NB>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(kern, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
   const int per_cu = (lds * 2 <= 160 * 1024 && KT <= 8) ? 2 : 1;
   // row groups of NW tiles, in whole sets of 8 XCDs; every group has `slices` workgroups
@@ -444,12 +439,7 @@ int launch_bf16(const RowsBf16Args& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(KT) * 3 * NB * 32 * 32 + 8 * 32 * NB * 32 * 2;
   static_assert(lds <= 160 * 1024, "weight image and output areas do not fit LDS");
   auto kern = gemm_rows_bf16_kernel<KT, NB>;
-  static bool configured = false;
-  if (!configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  SPMI_RAISE_LDS_LIMIT(kern, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   int64_t blocks = (n_tiles + 7) / 8;

@@ -391,12 +391,7 @@ template <int KT>
 int launch_mfma(const MlpArgs& a, hipStream_t st) {
   auto kernel = mlp_head_mfma_kernel<KT>;
   const size_t lds = static_cast<size_t>(KT) * kKStep + static_cast<size_t>(a.n_rest) * (kTailImage + 128);
-  static size_t configured = 0;
-  if (lds > configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  SPMI_RAISE_LDS_LIMIT(kernel, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
   const int64_t wgs = (n_tiles + kMfmaWaves - 1) / kMfmaWaves;
   kernel<<<static_cast<unsigned>(wgs < 512 ? wgs : 512), 64 * kMfmaWaves, lds, st>>>(a);
@@ -413,12 +408,7 @@ template <int O1P>
 int launch(const MlpArgs& a, hipStream_t st) {
   auto kernel = mlp_head_kernel<O1P>;
   const size_t lds = lds_bytes(a.I, O1P, a.rest_floats);
-  static size_t configured = 0;  // the dynamic-LDS limit is raised when a larger size shows up
-  if (lds > configured) {
-    SPMI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  SPMI_RAISE_LDS_LIMIT(kernel, lds);  // raised again when a larger size shows up
   const int64_t rows_per_block = 64 * kWaves;
   const unsigned grid = static_cast<unsigned>((a.M + rows_per_block - 1) / rows_per_block);
   kernel<<<grid, 64 * kWaves, lds, st>>>(a);
