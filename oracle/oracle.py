@@ -401,6 +401,32 @@ def citation_dispatch(edges: np.ndarray, nodes: np.ndarray, n_timestamps: int, t
     return src, dst, n, feat, ef
 
 
+def citation_tables_loops(graph_data, node_time: str, edges_key="edge_index", nodes_key="node_feat"):
+    """spiro/dtdg/dataloader.py:50-70 step by step (the per-edge loop and the id dictionary
+    included): (edges [t, src, dst], nodes [t, feat...], timestamps).  Parity unpinned: the
+    reference's test of this function downloads ogbn-arxiv (tests/dtdg/test_dataloader_torch.py)
+    and holds no fixture; what pins this restatement is the reading of those twenty lines."""
+    timestamps = np.unique(graph_data[node_time])
+    t_index = np.searchsorted(timestamps, graph_data[node_time][:, 0])
+    n = graph_data[nodes_key].shape[0]
+    t_index = np.reshape(t_index, (n, 1))
+    node_id = np.reshape(np.array(range(n)), (n, 1))
+    nodes = np.hstack((node_id, t_index, graph_data[nodes_key]))
+    nodes = nodes[nodes[:, 1].argsort()]
+    relabel = {old: new for old, new in zip(nodes[:, 0], np.array(range(n)))}
+    src_l, dst_l = [], []
+    for i in range(len(graph_data[edges_key][0])):
+        n1 = relabel[graph_data[edges_key][0][i]]
+        n2 = relabel[graph_data[edges_key][1][i]]
+        src_l.append(max(n1, n2))
+        dst_l.append(min(n1, n2))
+    sources, dest = np.array(src_l), np.array(dst_l)
+    edge_time = np.array([nodes[s][1] for s in sources])
+    edges = np.vstack((edge_time, sources, dest)).transpose()
+    edges = edges[edges[:, 0].argsort()]
+    return edges, nodes[:, 1:], timestamps
+
+
 # ----------------------------------------------------------------------------- recurrent cells
 def _sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)

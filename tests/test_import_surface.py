@@ -13,10 +13,12 @@ def test_reference_pipeline_imports():
     with pytest.raises(BackendNotSupportedError):
         set_backend(TENSORFLOW)
     from spiral_amd.automl.model_assembler import assembler
+    from spiral_amd.dtdg.dataloader import ogb_dataset, supported_ogb_datasets  # :10, used at :32-33
     from spiral_amd.dtdg.models.decoder.sequentialDecoders import GRU, LSTM, RNN
     from spiral_amd.dtdg.models.decoder.simpleDecoders import MLP
     from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder import implicitTimeModels as itm
     from spiral_amd.dtdg.models.encoder.implicitTimeEncoder.staticGraphEncoder import GAT, GCN, SGCN, GraphSage
 
     assert (GRU, LSTM, RNN) == (itm.GRU, itm.LSTM, itm.RNN)
-    assert all(callable(c) for c in (assembler, MLP, GCN, GAT, SGCN, GraphSage))
+    assert all(callable(c) for c in (assembler, MLP, GCN, GAT, SGCN, GraphSage, ogb_dataset))
+    assert "ogbn-arxiv" in supported_ogb_datasets()
