@@ -155,6 +155,15 @@ __global__ void split_weights_kernel(const float* __restrict__ w, int64_t rows, 
   out[base + 2 * rows * 16] = q2;
 }
 
+// Plane 1 of eight fp16-plane weights from their plane 0: p1 = fp16(w / 64) = p0 / 64 exactly
+// while p0 / 64 is a normal fp16 number (|w| >= 2^-8); below that the quotient is rounded once
+// more, by at most 2^-25, in a term that is multiplied by the 2^-5 |x| of the x residual.  The
+// weight image in memory keeps all three planes; the kernels here read two of them.
+__device__ __forceinline__ uint4 plane1_of(const uint4& p0) {
+  const f16x8 v = __builtin_bit_cast(f16x8, p0) * static_cast<_Float16>(0x1p-6f);
+  return __builtin_bit_cast(uint4, v);
+}
+
 template <int APT, int BPT>
 struct StageRegs {
   float4 a[APT];
@@ -217,8 +226,20 @@ __device__ __forceinline__ void store_stage(const StageRegs<APT, BPT>& r, char* 
 #pragma unroll
   for (int i = 0; i < BPT; ++i) {
     const int c = tid + i * THREADS;
-    if ((i + 1) * THREADS <= B16 || c < B16)
-      *reinterpret_cast<uint4*>(stage + A_BYTES + c * 16) = r.b[i];
+    if ((i + 1) * THREADS <= B16 || c < B16) {
+      if constexpr (MODE == MODE_F16X3) {
+        // planes 0 and 2 were read (B16 = their chunks, B16 / 2 each); plane 1 is made here
+        char* dst = stage + A_BYTES + c * 16;
+        if (c < B16 / 2) {  // wave-uniform: a plane is a multiple of 64 chunks
+          *reinterpret_cast<uint4*>(dst) = r.b[i];
+          *reinterpret_cast<uint4*>(dst + (B16 / 2) * 16) = plane1_of(r.b[i]);
+        } else {
+          *reinterpret_cast<uint4*>(dst + (B16 / 2) * 16) = r.b[i];
+        }
+      } else {
+        *reinterpret_cast<uint4*>(stage + A_BYTES + c * 16) = r.b[i];
+      }
+    }
   }
 }
 
@@ -313,8 +334,14 @@ __device__ __forceinline__ void stage_slice(int k, const StageRegs<APT, BPT>& r,
   } else {
     const int i = k - 5 * APT;
     const int c = tid + i * THREADS;
-    char* dst = ((i + 1) * THREADS <= B16 || c < B16) ? stage + A_BYTES + c * 16 : dump;
-    *reinterpret_cast<uint4*>(dst) = r.b[i];
+    const bool inside = (i + 1) * THREADS <= B16 || c < B16;
+    char* dst = stage + A_BYTES + c * 16;
+    if (c < B16 / 2) {  // plane 0 (wave-uniform): store it and the plane 1 made from it
+      *reinterpret_cast<uint4*>(inside ? dst : dump) = r.b[i];
+      *reinterpret_cast<uint4*>(inside ? dst + (B16 / 2) * 16 : dump) = plane1_of(r.b[i]);
+    } else {            // plane 2 sits one plane further than its chunk number says
+      *reinterpret_cast<uint4*>(inside ? dst + (B16 / 2) * 16 : dump) = r.b[i];
+    }
   }
 }
 
@@ -481,7 +508,10 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
   constexpr int A_BYTES = 3 * A_PLANE, B_BYTES = 3 * B_PLANE;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int APT = (kRows * kBK / 4) / THREADS;           // float4 of the A tile per thread
-  constexpr int B16 = B_BYTES / 16;                          // 16-byte chunks of the B tile
+  // 16-byte chunks of the B tile that are READ per K-step: all three planes of the bf16 pieces,
+  // planes 0 and 2 of the fp16 form (plane 1 is plane 0 / 64 and is made while staging, which
+  // takes a third off the weight stream, the larger part of what a K-step reads)
+  constexpr int B16 = (MODE == MODE_F16X3 ? 2 : 3) * (B_PLANE / 16);
   constexpr int BPT = (B16 + THREADS - 1) / THREADS;
   static_assert((kRows * kBK / 4) % THREADS == 0, "A tile must divide over the threads");
 
@@ -575,8 +605,15 @@ __global__ __launch_bounds__(256 * WC, JSUB == 1 ? 4 : 2) void split_cell_kernel
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int c = tid + i * THREADS;
-      const int ph = c / NC;  // plane * 2 + k half
-      const int nl = c % NC;
+      int ph, nl;  // plane * 2 + k half, tile row
+      if constexpr (MODE == MODE_F16X3) {
+        const int q = c / (2 * NC);  // 0: plane 0, 1: plane 2
+        ph = 4 * q + (c - q * 2 * NC) / NC;
+        nl = c % NC;
+      } else {
+        ph = c / NC;
+        nl = c % NC;
+      }
       const int brow = (c < B16) ? ph * GH + (nl / JC) * H + j0 + (nl % JC) : 0;
       boff[i] = brow * 8;
     }

@@ -890,17 +890,24 @@ def _fused_cell(kind, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write, h
             nv.stream()), "spmi_cell_fused_fwd")
 
 
-def gru_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
-    """The whole-table GRU kernel takes this layer (csrc/cell_rows.hip): fp16-plane arithmetic
-    selected, shapes it is built for, nothing tracked for a backward pass.  `params`: the
-    layer's other parameters (w_ih, b_ih, b_hh); the kernel keeps no graph, so one trainable
-    tensor among them under grad mode sends the layer to the tracked cell instead."""
+def _whole_table_ok(supported: str, x: torch.Tensor, w_hh: torch.Tensor, params) -> bool:
+    """Common conditions of the whole-table cell kernels (csrc/cell_rows.hip): fp16-plane
+    arithmetic selected, a layout the kernel reads, a shape `supported` (the library's predicate
+    of that name) accepts, and nothing tracked for a backward pass.  The kernels keep no graph,
+    so one trainable tensor among x and the layer's parameters under grad mode sends the layer
+    to the tracked cell instead."""
     tracked = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
     return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
-            and bool(nv.lib().spmi_gru_rows_supported(x.shape[1], w_hh.shape[1])))
+            and bool(getattr(nv.lib(), supported)(x.shape[1], w_hh.shape[1])))
+
+
+def gru_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
+    """The whole-table GRU kernel takes this layer.  `params`: the layer's other parameters
+    (w_ih, b_ih, b_hh)."""
+    return _whole_table_ok("spmi_gru_rows_supported", x, w_hh, params)
 
 
 def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out: torch.Tensor,
@@ -925,12 +932,7 @@ def gru_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
 
 def rnn_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
     """The whole-table tanh-RNN kernel takes this layer (conditions as for `gru_rows_ok`)."""
-    tracked = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
-    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
-            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
-            and bool(nv.lib().spmi_rnn_rows_supported(x.shape[1], w_hh.shape[1])))
+    return _whole_table_ok("spmi_rnn_rows_supported", x, w_hh, params)
 
 
 def rnn_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out: torch.Tensor,
@@ -954,12 +956,7 @@ def rnn_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, h_out:
 
 def lstm_rows_ok(x: torch.Tensor, w_hh: torch.Tensor, *params: Optional[torch.Tensor]) -> bool:
     """The whole-table LSTM kernel takes this layer (conditions as for `gru_rows_ok`)."""
-    tracked = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad for t in (x, w_hh) + tuple(params))
-    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
-            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
-            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and not tracked
-            and bool(nv.lib().spmi_lstm_rows_supported(x.shape[1], w_hh.shape[1])))
+    return _whole_table_ok("spmi_lstm_rows_supported", x, w_hh, params)
 
 
 def lstm_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, c_in: torch.Tensor,
