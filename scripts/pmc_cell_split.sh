@@ -1,0 +1,20 @@
+#!/bin/bash
+# Counter passes for the row-tile cell kernel at H = 512; one rocprofv3 run per pass (<= 8 SQ counters).
+set -e
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+out=gpurun_out/pmc_cell
+mkdir -p $out
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --kernel-trace -d $out/p1 -o p1 --output-format csv -- python3 scripts/pmc_cell_split.py > $out/p1.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace -d $out/p2 -o p2 --output-format csv -- python3 scripts/pmc_cell_split.py > $out/p2.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_INSTS_SALU --kernel-trace -d $out/p3 -o p3 --output-format csv -- python3 scripts/pmc_cell_split.py > $out/p3.log 2>&1
+python3 - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_cell/p*/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "split_cell" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        print(f"{k:36s} {sum(v)/len(v):16.0f}  (n={len(v)})")
+PY
