@@ -9,7 +9,7 @@ from spiral_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 m = 1_000_000
-for i, dims in ((128, [10, 20, 10, 5, 1]), (256, [10, 20, 10, 5, 1]), (64, [32, 32, 1]), (96, [10, 20, 10, 5, 1])):
+for i, dims in ((128, [10, 20, 10, 5, 1]), (256, [10, 20, 10, 5, 1]), (64, [32, 32, 1]), (96, [10, 20, 10, 5, 1]), (512, [10, 20, 10, 5, 1]), (384, [10, 20, 10, 5, 1])):
     x = torch.randn(m, i, device=dev)
     layers, w = [], i
     for j, d in enumerate(dims):

@@ -8,8 +8,9 @@
 // HBM; here the [N, I] input is read once and only the [N, out] result is written.
 // HBM-bound: N * (I + out) * 4 bytes.
 //
-// Two kernels.  Up to I = 256 the whole head runs on the fp16 matrix cores
-// (mlp_head_mfma_kernel, below); wider inputs take the all-VALU kernel described next.
+// Two kernels.  For I a multiple of 32 up to 256, and for 320, 384, 448 and 512, the whole head
+// runs on the fp16 matrix cores (mlp_head_mfma_kernel, below); other widths take the all-VALU
+// kernel described next.
 //
 // Mapping (VALU kernel): a wave owns 64 rows, one per lane.  The input arrives in 32-column chunks
 // (coalesced 128-byte row segments, the next chunk in flight while the current one is
@@ -236,12 +237,17 @@ __device__ __forceinline__ f32x16 mfma3(const char* img, const f16x8& x0, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, x0, acc, 0, 0, 0);
 }
 
-template <int KT>
-__global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpArgs p) {
+// KT K-steps of a row are in registers at a time; wider inputs (KC > 1 chunks of 16 KT inputs)
+// pass through the same registers chunk by chunk while the first layer's sums stay in their
+// accumulators.  The first layer's image of all KT KC K-steps stays in LDS, which then leaves
+// room for one workgroup per CU: it has eight waves instead of four.
+template <int KT, int KC>
+__global__ __launch_bounds__(64 * (KC > 1 ? 2 : 1) * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpArgs p) {
   static_assert(KT % 2 == 0, "rows are read in pairs of K-steps");
+  constexpr int NW = (KC > 1 ? 2 : 1) * kMfmaWaves;
   extern __shared__ float4 smem4[];
-  char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT][3][2][32][8] fp16
-  char* s_tail = s_l1 + KT * kKStep;                       // [n_rest][2][3][2][32][8] fp16
+  char* s_l1 = reinterpret_cast<char*>(smem4);             // [KT KC][3][2][32][8] fp16
+  char* s_tail = s_l1 + KT * KC * kKStep;                  // [n_rest][2][3][2][32][8] fp16
   float* s_bias = reinterpret_cast<float*>(s_tail + p.n_rest * kTailImage);  // [n_rest][32]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
   const int lh = lane >> 5;
 
   // W1 (given [I][o1p], zero-padded columns) -> planes in the A layout, once per workgroup
-  for (int idx = tid; idx < KT * 16 * 32; idx += 64 * kMfmaWaves) {
+  for (int idx = tid; idx < KT * KC * 16 * 32; idx += 64 * NW) {
     const int k = idx >> 5, f = idx & 31;
     const float v = f < p.o1p ? p.w1t[k * p.o1p + f] : 0.0f;
     _Float16 q0, q1, q2;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
     const float* w = p.rest;
     for (int l = 0; l < p.n_rest; ++l) {
       const int in_w = p.in_w[l], out_w = p.out_w[l];
-      for (int idx = tid; idx < 2 * 32 * 16; idx += 64 * kMfmaWaves) {
+      for (int idx = tid; idx < 2 * 32 * 16; idx += 64 * NW) {
         const int t = idx >> 9, f = (idx >> 4) & 31, kappa = idx & 15;
         const int unit = (kappa & 3) + 8 * (2 * t + ((kappa & 7) >> 2)) + 4 * (kappa >> 3);
         const float v = (f < out_w && unit < in_w) ? w[f * in_w + unit] : 0.0f;
@@ -288,8 +294,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
   __syncthreads();
 
   const int64_t n_tiles = (p.M + 31) / 32;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kMfmaWaves;
-  int64_t tile = static_cast<int64_t>(blockIdx.x) * kMfmaWaves + wave;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
+  int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
   if (tile >= n_tiles) return;  // no barrier below
 
   float b1[16];
@@ -315,24 +321,31 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
 
   while (tile < n_tiles) {
     const int64_t next = tile + stride;
-    int64_t r = (next < n_tiles ? next : tile) * 32 + lr;  // last pass re-reads its own tile
-    r = r < p.M ? r : p.M - 1;
-    const float* src = p.x + r * p.ldx + 16 * lh;
+    int64_t r_own = tile * 32 + lr;
+    r_own = r_own < p.M ? r_own : p.M - 1;
+    int64_t r_next = (next < n_tiles ? next : tile) * 32 + lr;  // last pass re-reads its own tile
+    r_next = r_next < p.M ? r_next : p.M - 1;
 
     f32x16 cur;
 #pragma unroll
     for (int e = 0; e < 16; ++e) cur[e] = b1[e];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      const float v[8] = {a[t][0].x, a[t][0].y, a[t][0].z, a[t][0].w,
-                          a[t][1].x, a[t][1].y, a[t][1].z, a[t][1].w};
-      f16x8 x0, x1, x2;
-      split8(v, x0, x1, x2);
-      a[t][0] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1));
-      a[t][1] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1) + 4);
-      __builtin_amdgcn_sched_barrier(0);  // keeps the reloads from being hoisted over the tile
-      cur = mfma3(s_l1 + t * kKStep + frag, x0, x1, x2, cur);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < KC; ++c) {
+      // what refills the registers: the next chunk of this tile, or the first of the next tile
+      const float* src = c + 1 < KC ? p.x + r_own * p.ldx + 16 * lh + (c + 1) * 16 * KT
+                                    : p.x + r_next * p.ldx + 16 * lh;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const float v[8] = {a[t][0].x, a[t][0].y, a[t][0].z, a[t][0].w,
+                            a[t][1].x, a[t][1].y, a[t][1].z, a[t][1].w};
+        f16x8 x0, x1, x2;
+        split8(v, x0, x1, x2);
+        a[t][0] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1));
+        a[t][1] = *reinterpret_cast<const float4*>(src + 32 * (t >> 1) + 8 * (t & 1) + 4);
+        __builtin_amdgcn_sched_barrier(0);  // keeps the reloads from being hoisted over the tile
+        cur = mfma3(s_l1 + (c * KT + t) * kKStep + frag, x0, x1, x2, cur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (p.relu1) {
 #pragma unroll
@@ -387,14 +400,16 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void mlp_head_mfma_kernel(MlpAr
   }
 }
 
-template <int KT>
+template <int KT, int KC = 1>
 int launch_mfma(const MlpArgs& a, hipStream_t st) {
-  auto kernel = mlp_head_mfma_kernel<KT>;
-  const size_t lds = static_cast<size_t>(KT) * kKStep + static_cast<size_t>(a.n_rest) * (kTailImage + 128);
+  auto kernel = mlp_head_mfma_kernel<KT, KC>;
+  constexpr int NW = (KC > 1 ? 2 : 1) * kMfmaWaves;
+  const size_t lds = static_cast<size_t>(KT * KC) * kKStep + static_cast<size_t>(a.n_rest) * (kTailImage + 128);
   SPMI_RAISE_LDS_LIMIT(kernel, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
-  const int64_t wgs = (n_tiles + kMfmaWaves - 1) / kMfmaWaves;
-  kernel<<<static_cast<unsigned>(wgs < 512 ? wgs : 512), 64 * kMfmaWaves, lds, st>>>(a);
+  const int64_t wgs = (n_tiles + NW - 1) / NW;
+  constexpr int64_t max_wgs = KC > 1 ? 256 : 512;  // what is resident at once
+  kernel<<<static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 64 * NW, lds, st>>>(a);
   SPMI_CHECK_LAUNCH("mlp_head_mfma");
   return SPMI_OK;
 }
@@ -416,6 +431,11 @@ int launch(const MlpArgs& a, hipStream_t st) {
   return SPMI_OK;
 }
 
+// Input widths the matrix-core kernel is instantiated for (the switch in spmi_mlp_head_fwd).
+bool mfma_input_width(int64_t I) {
+  return (I % 32 == 0 && I >= 32 && I <= 256) || I == 320 || I == 384 || I == 448 || I == 512;
+}
+
 }  // namespace
 
 extern "C" {
@@ -424,7 +444,9 @@ int spmi_mlp_head_supported(int64_t I, int32_t out1, int32_t n_rest, const int32
   if (I < kChunk || I % kChunk || out1 < 1 || out1 > kMaxWidth || n_rest < 0 || n_rest > kMaxRest)
     return 0;
   const int o1p = out1 <= 8 ? 8 : (out1 <= 16 ? 16 : 32);
-  if (I * o1p > kMaxW1) return 0;
+  // the matrix-core kernel keeps the first layer as fp16 planes of 32 padded units whatever
+  // its width; the other kernel keeps it in fp32
+  if (!mfma_input_width(I) && I * o1p > kMaxW1) return 0;
   int64_t floats = 0;
   int width = out1;
   for (int l = 0; l < n_rest; ++l) {
@@ -464,7 +486,7 @@ int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const f
   a.final_act = final_act; a.out = out; a.ldo = ldo;
   a.o1p = out1 <= 8 ? 8 : (out1 <= 16 ? 16 : 32);
   hipStream_t st = spmi::as_stream(stream);
-  switch (I) {  // up to 256 inputs a wave holds its rows in registers: the matrix-core kernel
+  switch (I) {  // a wave holds up to 256 inputs of its rows in registers: the matrix-core kernel
     case 32: return launch_mfma<2>(a, st);
     case 64: return launch_mfma<4>(a, st);
     case 96: return launch_mfma<6>(a, st);
@@ -473,6 +495,10 @@ int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const f
     case 192: return launch_mfma<12>(a, st);
     case 224: return launch_mfma<14>(a, st);
     case 256: return launch_mfma<16>(a, st);
+    case 320: return launch_mfma<10, 2>(a, st);
+    case 384: return launch_mfma<12, 2>(a, st);
+    case 448: return launch_mfma<14, 2>(a, st);
+    case 512: return launch_mfma<16, 2>(a, st);
     default: break;
   }
   if (out1 <= 8) return launch<8>(a, st);

@@ -39,8 +39,13 @@ def _randomise(mlp, seed):
     (70_000, 128, [17, 31], 32, "linear"),
     (5001, 96, [10, 20], 1, "linear"),
     (4100, 160, [32, 5], 4, "sigmoid"),
-    (4500, 512, [10, 20], 1, "linear"),            # more than 256 inputs: the all-VALU kernel
+    (4500, 512, [10, 20], 1, "linear"),            # more than 256 inputs: two chunks per row
     (4200, 320, [16], 2, "tanh"),
+    (5000, 384, [32], 3, "linear"),
+    (4300, 448, [5], 1, "sigmoid"),
+    (4400, 512, [32, 8], 1, "linear"),             # 512 x 32 first layer
+    (70_001, 512, [10, 20, 10, 5], 1, "linear"),   # many tiles per wave, ragged last tile
+    (4100, 288, [10], 1, "linear"),                # a width only the all-VALU kernel takes
 ])
 def test_fused_head_equals_layerwise(dev, n, i, dims, out, act):
     torch.manual_seed(n % 97)
