@@ -509,8 +509,10 @@ int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K
  *            layout followed by its bias [out] (zeros if none), back to back,
  *            device memory; rest_out / rest_relu are HOST arrays of n_rest ints;
  *   relu flags per layer; final_act: 0 none, 1 sigmoid, 2 relu, 3 tanh.
- * Limits (spmi_mlp_head_supported): I a multiple of 32, widths <= 32,
- * I * P <= 8192, at most 7 layers after the first.
+ * Limits (spmi_mlp_head_supported): I a multiple of 32, widths <= 32, at most
+ * 7 layers after the first; I * P <= 8192 unless I is one of the widths the
+ * matrix-core kernel is built for (multiples of 32 up to 256, 320, 384, 448,
+ * 512), which has no such bound.
  * ---------------------------------------------------------------------- */
 int spmi_mlp_head_supported(int64_t I, int32_t out1, int32_t n_rest, const int32_t* rest_out);
 int spmi_mlp_head_fwd(const float* x, int64_t ldx, int64_t M, int64_t I, const float* w1t,
