@@ -251,7 +251,6 @@ __device__ __forceinline__ void mfma_stage(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
                                            const char* sb) {
   using C = Cell<CELL>;
   constexpr int NB = C::NG * JSUB;
-  constexpr int ROWB = kBK * 2;
   const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa);
   const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + A_PLANE);
   const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(sa + 2 * A_PLANE);
@@ -358,7 +357,6 @@ __device__ __forceinline__ void piped_step(f32x16 (&acc)[JSUB][Cell<CELL>::NACC]
                                            int tid) {
   using C = Cell<CELL>;
   constexpr int NB = C::NG * JSUB;
-  constexpr int ROWB = kBK * 2;
   constexpr int SLOTS = 3 * NB;
   constexpr int SLICES = 5 * APT + BPT;
   constexpr int LEAD = SLOTS - SLICES < 0 ? 0 : (SLOTS - SLICES < 5 ? SLOTS - SLICES : 5);

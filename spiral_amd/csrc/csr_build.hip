@@ -106,22 +106,59 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const KeyT* __rest
 }
 
 // ---- pass kernel 2: one workgroup per digit scans that digit's tile counts ------
+// A wave owns a contiguous quarter of the row and walks it in strips of 64 consecutive
+// counts, one per lane (a load or store instruction covers 256 contiguous bytes), eight
+// strips in flight at a time; the running sum travels in a register.  With a million tiles'
+// worth of edges a thread-contiguous split of the row (every lane of a load in a cache line of
+// its own) took 0.16 ms per pass.
 __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist,
                                                               int n_tiles,
                                                               uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_wave[kWaves];
+  constexpr int kStrips = 8;
   uint32_t* row = hist + static_cast<size_t>(blockIdx.x) * n_tiles;
-  const int per = (n_tiles + kThreads - 1) / kThreads;
-  const int begin = min(static_cast<int>(threadIdx.x) * per, n_tiles);
-  const int end = min(begin + per, n_tiles);
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int span = ((n_tiles + kWaves - 1) / kWaves + 63) / 64 * 64;
+  const int begin = min(wave * span, n_tiles);
+  const int end = min(begin + span, n_tiles);
+
   uint32_t sum = 0;
-  for (int i = begin; i < end; ++i) sum += row[i];
-  uint32_t total;
-  uint32_t run = block_exclusive_scan(sum, s_wave, &total);
-  for (int i = begin; i < end; ++i) {
-    uint32_t c = row[i];
-    row[i] = run;
-    run += c;
+  for (int i0 = begin; i0 < end; i0 += 64 * kStrips) {
+    uint32_t c[kStrips];
+#pragma unroll
+    for (int j = 0; j < kStrips; ++j) {
+      const int i = i0 + 64 * j + lane;
+      c[j] = i < end ? row[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kStrips; ++j) sum += c[j];
+  }
+  sum = wave_inclusive_scan(sum);  // lane 63: the wave's total
+  if (lane == 63) s_wave[wave] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    const uint32_t c = s_wave[w];
+    if (w < wave) run += c;
+    total += c;
+  }
+
+  for (int i0 = begin; i0 < end; i0 += 64 * kStrips) {
+    uint32_t c[kStrips];
+#pragma unroll
+    for (int j = 0; j < kStrips; ++j) {
+      const int i = i0 + 64 * j + lane;
+      c[j] = i < end ? row[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kStrips; ++j) {
+      const int i = i0 + 64 * j + lane;
+      const uint32_t incl = wave_inclusive_scan(c[j]);
+      if (i < end) row[i] = run + incl - c[j];
+      run += __shfl(incl, 63);
+    }
   }
   if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
@@ -282,11 +319,6 @@ __global__ __launch_bounds__(kThreads) void csr_finalize_kernel(const uint32_t* 
   // rows after the last key (and indptr[N]) point at E
   const bool last = valid && (i == E - 1);
   wave_fill_gaps(indptr, k + 1, last ? (N - k) : 0, static_cast<int32_t>(E));
-}
-
-__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
 }
 
 __global__ void indptr_to_degree_kernel(const int32_t* __restrict__ indptr, int64_t N,
