@@ -23,9 +23,12 @@ def timed(fn, iters=20):
 
 dev = torch.device("cuda:0")
 m = 1_000_000
-for k, n in ((128, 128), (128, 64), (64, 128), (128, 32), (32, 32), (256, 128), (384, 128)):
+for k, n in ((128, 128), (128, 64), (64, 128), (128, 32), (32, 32), (256, 128), (384, 128), (256, 512)):
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) * 0.1
+    if not ops._gemm_rows_ok(x, k, n):
+        print(f"K={k} N={n}: not taken by this library", flush=True)
+        continue
     t_k = timed(lambda: ops.gemm_rows(x, w))
     wt = w.t().contiguous()
     t_l = timed(lambda: x @ wt)

@@ -6,9 +6,10 @@
 // fp32 in, fp32 out, on the fp16 matrix cores with the three-plane operand format of
 // cell_split.hip (p0 = fp16(v), p1 = fp16(v/64), p2 = fp16((v - p0)*64); x*w = p0*p0 + p1*p2 +
 // p2*p1, fp32 accumulation): sums land closer to float64 than an fp32 FMA chain.  The rows of
-// X may hold any finite fp32 value: a wave has the whole row in registers before it starts
-// on it, so every row is multiplied by a power of two that puts its largest magnitude in
-// [2^13, 2^14) (exact), and the accumulators by the inverse power at the end.  Raw node
+// X may hold any finite fp32 value: a wave has the whole row (or, for K = 256 and 384, a chunk
+// of 128 columns of it) in registers before it starts on it, so every row (chunk) is multiplied
+// by a power of two that puts its largest magnitude in [2^13, 2^14) (exact), and the
+// accumulators by the inverse power at the end (of the chunk).  Raw node
 // features such as degree counts can exceed fp16's 65504; without the scaling such a row
 // would come out as inf/NaN.  The weights must lie within +-65504 / 64.
 //
@@ -19,10 +20,10 @@
 //  * X never touches LDS: the A fragment of v_mfma_f32_32x32x16_f16 is eight consecutive k
 //    of one row per lane, i.e. two float4 loads straight from global memory, split into the
 //    three planes in registers;
-//  * a wave owns 32 rows x all N columns and keeps the whole K of its rows in registers
-//    (K/2 VGPRs); as soon as the slice of K-step t is split, the same registers receive the
-//    K-step t of the wave's next tile, so 16 KB per wave (128 KB per CU) are in flight while
-//    the matrix cores work;
+//  * a wave owns 32 rows x all N columns and keeps up to 128 columns of its rows in registers
+//    (64 VGPRs); as soon as the slice of K-step t is split, the same registers receive the
+//    K-step t of the next chunk or of the wave's next tile, so 16 KB per wave (128 KB per CU)
+//    are in flight while the matrix cores work;
 //  * waves are independent after the weight load: no barrier in the loop;
 //  * wide outputs (N > 128) and K = 256, 384 are cut into column slices of 128 (64 for
 //    K = 256, 384) that fit LDS: the workgroups that hold the slices of one row range run on one XCD
@@ -72,15 +73,20 @@ __device__ __forceinline__ void split8(const float4& lo, const float4& hi, float
   }
 }
 
-template <int KT, int NB>
+// KT K-steps (16 KT columns) of a row are in registers at a time.  KC = 1: that is the whole
+// row.  KC > 1: a row passes through the registers in KC chunks, each with a power-of-two
+// scale of its own, and the chunks' sums are added up in a second accumulator set after the
+// inverse scale; 64 row registers instead of 16 KT KC / 2 keep two waves on a SIMD for
+// K = 256 and 384, where one wave with the whole row had nothing to run under its own waits.
+template <int KT, int NB, int KC>
 __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_kernel(RowsArgs p) {
-  // K = 256 keeps 128 registers of row data per lane: four waves per workgroup, one per SIMD,
-  // with the whole register file; the smaller shapes run eight waves (two per SIMD).
+  // More than 128 columns in registers at once: four waves per workgroup, one per SIMD, with
+  // the whole register file; otherwise eight waves (two per SIMD).
   constexpr int NW = KT > 8 ? 4 : 8;
   constexpr int N = NB * 32;
   constexpr int PLANE = N * 32;           // bytes of one plane of one K-step
   constexpr int KSTEP = 3 * PLANE;        // bytes of one K-step
-  constexpr int B16 = KT * KSTEP / 16;    // 16-byte chunks of the weight image
+  constexpr int B16 = KT * KC * KSTEP / 16;  // 16-byte chunks of the weight image
   extern __shared__ uint4 smem4[];
   const char* smem = reinterpret_cast<const char*>(smem4);
 
@@ -145,9 +151,32 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   while (tile < n_tiles) {
     const int64_t next = tile + stride;
     // the last iteration re-reads its own tile: valid memory, nothing is done with it
-    const float* src = row_ptr(next < n_tiles ? next : tile);
+    const float* src_next = row_ptr(next < n_tiles ? next : tile);
+    const float* src_own = row_ptr(tile);
 
     f32x16 acc[NB];
+    f32x16 tot[KC > 1 ? NB : 1];  // sums of the chunks already done, in the row's own units
+    if constexpr (KC > 1) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[nb][e] = 0.0f;
+    }
+
+    // the row scales of this tile, fetched under the matrix work (rows past M: clamped)
+    float rs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int64_t r = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      r = r < p.M ? r : p.M - 1;
+      rs[e] = p.row_scale ? p.row_scale[r] : 1.0f;
+    }
+
+    float up, down;
+#pragma unroll 1
+    for (int c = 0; c < KC; ++c) {
+    // what refills the registers: the next chunk of this tile, or the first of the next tile
+    const float* src = c + 1 < KC ? src_own + (c + 1) * 16 * KT : src_next;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -155,7 +184,6 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
 
     // Power-of-two scale of this lane's row (the lane pair l, l ^ 32 holds one row): the
     // largest magnitude goes to [2^13, 2^14), a zero or non-finite row is left alone.
-    float up, down;
     {
       float m = 0.0f;
 #pragma unroll
@@ -172,15 +200,6 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
       down = __uint_as_float(static_cast<uint32_t>(127 - sh) << 23);
     }
 
-    // the row scales of this tile, fetched under the matrix work (rows past M: clamped)
-    float rs[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int64_t r = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      r = r < p.M ? r : p.M - 1;
-      rs[e] = p.row_scale ? p.row_scale[r] : 1.0f;
-    }
-
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       f16x8 p0, p1, p2;
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
       // Keep the K-steps apart: left alone, the scheduler hoists every reload to the top of
       // the tile and then needs a second copy of the whole row in registers.
       __builtin_amdgcn_sched_barrier(0);
-      const char* sb = smem + t * KSTEP + b_rd;
+      const char* sb = smem + (c * KT + t) * KSTEP + b_rd;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const f16x8 b0 = *reinterpret_cast<const f16x8*>(sb + nb * 32 * 16);
@@ -201,6 +220,18 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (KC > 1) {  // this chunk's sums, back in the row's own units
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur));
+        const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(down), ur + 4));
+        const float dn = lh ? d1 : d0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tot[nb][e] = __builtin_fmaf(acc[nb][e], dn, tot[nb][e]);
+      }
+    }
+    }  // chunks
 
     // C layout of the 32x32 MFMA: element e of lane l is row (e&3) + 8 (e>>2) + 4 (l>>5),
     // column l&31: a store covers two 128-byte row segments.
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
         const float dn = lh ? d1 : d0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          float v = acc[nb][e] * dn + bias[nb];
+          float v = (KC > 1 ? tot[nb][e] : acc[nb][e] * dn) + bias[nb];
           if constexpr (ACT == 1) v = fmaxf(v, 0.0f);
           else if constexpr (ACT == 2) v = v > 0.0f ? v : v * p.slope;
           o[voff + nb * 32] = v * rs[e];
@@ -244,11 +275,11 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   }
 }
 
-template <int KT, int NB>
+template <int KT, int NB, int KC = 1>
 int launch(const RowsArgs& a, hipStream_t st) {
-  constexpr size_t lds = static_cast<size_t>(KT) * 3 * NB * 32 * 32;
+  constexpr size_t lds = static_cast<size_t>(KT) * KC * 3 * NB * 32 * 32;
   static_assert(lds <= 160 * 1024, "weight image does not fit LDS");
-  auto kern = gemm_rows_kernel<KT, NB>;
+  auto kern = gemm_rows_kernel<KT, NB, KC>;
   SPMI_RAISE_LDS_LIMIT(kern, lds);
   const int64_t n_tiles = (a.M + 31) / 32;
   const int per_cu = (lds * 2 <= 160 * 1024 && KT <= 8) ? 2 : 1;
@@ -460,20 +491,22 @@ int launch_bf16_n(const RowsBf16Args& a, int64_t N, hipStream_t st) {
 }
 
 // Columns per workgroup: the whole weight up to 128 columns, slices of 128 (K <= 128) or 64
-// (K = 256, 384) beyond.
+// (K = 256, 384) beyond: what fits LDS as three planes.  (K = 512 would leave 32 columns per
+// workgroup; built and measured, it ran level with the library GEMM, 3.7 ms at 1M x 512 x 512,
+// and is not offered.)
 int slice_width(int64_t K, int64_t N) {
   if (K == 256 || K == 384) return N % 64 == 0 ? 64 : 0;
   if (N <= 128) return (N % 32 == 0) ? static_cast<int>(N) : 0;
   return N % 128 == 0 ? 128 : 0;
 }
 
-template <int KT>
+template <int KT, int KC = 1>
 int launch_n(RowsArgs& a, int64_t K, int64_t N, hipStream_t st) {
   const int w = slice_width(K, N);
   a.n_total = static_cast<int>(N);
   a.slices = static_cast<int>(N / w);
-  if constexpr (KT > 8) {
-    return launch<KT, 2>(a, st);
+  if constexpr (KC > 1) {
+    return launch<KT, 2, KC>(a, st);
   } else {
     switch (w) {
       case 32: return launch<KT, 1>(a, st);
@@ -548,8 +581,8 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
   if (K == 32) return launch_n<2>(a, K, N, st);
   if (K == 64) return launch_n<4>(a, K, N, st);
   if (K == 128) return launch_n<8>(a, K, N, st);
-  if (K == 256) return launch_n<16>(a, K, N, st);
-  return launch_n<24>(a, K, N, st);
+  if (K == 256) return launch_n<8, 2>(a, K, N, st);  // wider rows pass in chunks of 128 columns
+  return launch_n<8, 3>(a, K, N, st);
 }
 
 }  // extern "C"

@@ -37,11 +37,12 @@ def test_all_shapes(dev, k, n):
 
 
 @pytest.mark.parametrize("k,n", [(256, 512), (256, 64), (256, 192), (128, 256), (64, 512), (128, 384),
-                                 (384, 128), (384, 64)])
+                                 (384, 128), (384, 64), (384, 256)])
 def test_wide_outputs_in_column_slices(dev, k, n):
-    """N > 128 and K = 256, 384 (the 256 -> 512 projection of the wide-feature workload; the
-    gate gradients [rows, 3 x 128] times W_ih of a GRU layer's backward): column slices
-    computed by different workgroups, with bias, activation and row scale per slice."""
+    """N > 128 and K = 256, 384 (the 256 -> 512 projection of the
+    wide-feature workload; the gate gradients [rows, 3 x 128] times W_ih of a GRU layer's
+    backward): column slices computed by different workgroups, with bias, activation and row
+    scale per slice; rows wider than 128 columns pass through the registers in chunks."""
     assert nv.lib().spmi_gemm_rows_supported(k, n)
     gen = torch.Generator().manual_seed(k + n)
     for m in (1, 33, 5000 + 13):
@@ -133,6 +134,27 @@ def test_rows_of_any_magnitude_and_bad_shapes(dev):
     keep = torch.ones(4096, dtype=torch.bool)
     keep[200] = keep[201] = False
     assert torch.isfinite(out[keep.to(dev)]).all()
+    # rows wider than 128 columns are scaled chunk by chunk: chunks of very different size in
+    # one row, a huge row, a tiny row, a non-finite value in the second chunk only
+    xw = torch.randn(4100, 256, generator=gen)
+    xw[7, :128] *= 1.0e-20
+    xw[7, 128:] *= 1.0e20
+    xw[8] *= 3.0e30
+    xw[9] *= 1.0e-30
+    xw[10, 128:] = 0.0
+    xw = xw.to(dev)
+    ww = (torch.randn(64, 256, generator=gen) * 0.1).to(dev)
+    outw = ops.gemm_rows(xw, ww).double().cpu()
+    wantw = _ref(xw, ww, None, None)
+    scalew = wantw.abs().amax(dim=1, keepdim=True).clamp(min=1e-300)
+    assert torch.isfinite(outw).all()
+    assert float(((outw - wantw).abs() / scalew).max()) < 2e-6
+    xw[11, 200] = float("inf")
+    outw = ops.gemm_rows(xw, ww)
+    assert not torch.isfinite(outw[11]).any()
+    keepw = torch.ones(4100, dtype=torch.bool)
+    keepw[11] = False
+    assert torch.isfinite(outw[keepw.to(dev)]).all()
     assert not nv.lib().spmi_gemm_rows_supported(48, 32)
     assert not nv.lib().spmi_gemm_rows_supported(128, 200)
     with pytest.raises(nv.SpmiError):
