@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * (KC > 1 ? 2 : 1) * kMfmaWaves, 2) void mlp_hea
     f32x16 cur;
 #pragma unroll
     for (int e = 0; e < 16; ++e) cur[e] = b1[e];
-#pragma unroll
+#pragma unroll 1  // unrolled, the chunks' loads are scheduled into each other and registers spill
     for (int c = 0; c < KC; ++c) {
       // what refills the registers: the next chunk of this tile, or the first of the next tile
       const float* src = c + 1 < KC ? p.x + r_own * p.ldx + 16 * lh + (c + 1) * 16 * KT
