@@ -398,11 +398,14 @@ int spmi_lstm_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t
  * Replaces `torch.matmul(feat, weight)` inside dgl GraphConv.forward (call sites
  * staticGraphEncoder.py:113,116; likewise SGConv / SAGEConv's fc layers) and the Linear
  * layers of the decoders (simpleDecoder.py:43-46) for K in {32, 64, 128} with
- * N in {32, 64, 96, 128} or any multiple of 128, and K = 256 or 384 with N a multiple of 64 (wide
- * outputs are computed in column slices by workgroups that share an XCD's L2).  fp32 results from the fp16 matrix cores with the three-plane
+ * N in {32, 64, 96, 128} or any multiple of 128, and K = 256, 384 or 512 with N a multiple
+ * of 64 (wide outputs are computed in column slices by workgroups that share an XCD's L2;
+ * K = 512 is two launches, the second adding its half of the sums to `out`, which holds
+ * the first half in between).  fp32 results from the fp16 matrix cores with the three-plane
  * operand format of spmi_cell_f16x3_fwd (same accuracy).  The rows of x may hold any finite
- * fp32 value (each row is scaled by a power of two before it is split and its results by the
- * inverse; a non-finite entry makes its own row non-finite); |W| <= 1023;
+ * fp32 value (each row, in chunks of 128 columns, is scaled by a power of two before it is
+ * split and its sums by the inverse; a non-finite entry makes its own row non-finite);
+ * |W| <= 1023;
  * w_planes = spmi_split_f16x3(W, N, K).  The weight planes stay in LDS and x streams from
  * HBM straight into the matrix cores, so the kernel runs at memory speed:
  * M*(K+N)*4 bytes.  act: 0 none, 1 relu, 2 leaky_relu(slope).  bias nullable.

@@ -23,7 +23,7 @@ def timed(fn, iters=20):
 
 dev = torch.device("cuda:0")
 m = 1_000_000
-for k, n in ((128, 128), (128, 64), (64, 128), (128, 32), (32, 32), (256, 128), (384, 128), (256, 512)):
+for k, n in ((128, 128), (128, 64), (64, 128), (128, 32), (32, 32), (256, 128), (384, 128), (256, 512), (512, 128), (512, 512)):
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) * 0.1
     if not ops._gemm_rows_ok(x, k, n):

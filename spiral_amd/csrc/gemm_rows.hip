@@ -52,6 +52,7 @@ struct RowsArgs {
   int64_t ldo;
   int n_total;  // columns of the whole weight; a workgroup computes NB * 32 of them
   int slices;   // n_total / (NB * 32)
+  int accumulate;  // chunked kernels only: add what `out` holds before bias and activation
 };
 
 // The three planes of eight consecutive k of one row, the row's power-of-two scale applied on
@@ -241,9 +242,10 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
     // One decision per tile, not per element: the activation and whether every row of the tile
     // exists are wave-uniform, and asked inside the loops they cost a scalar branch or two for
     // each of the 16 NB results of a lane.
-    auto finish = [&](auto act_tag, auto whole_tag) {
+    auto finish = [&](auto act_tag, auto whole_tag, auto add_tag) {
       constexpr int ACT = decltype(act_tag)::value;
       constexpr bool WHOLE = decltype(whole_tag)::value;
+      constexpr bool ADD = decltype(add_tag)::value;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ur = (e & 3) + 8 * (e >> 2);
@@ -258,19 +260,28 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           float v = (KC > 1 ? tot[nb][e] : acc[nb][e] * dn) + bias[nb];
+          if constexpr (ADD) v += o[voff + nb * 32];
           if constexpr (ACT == 1) v = fmaxf(v, 0.0f);
           else if constexpr (ACT == 2) v = v > 0.0f ? v : v * p.slope;
           o[voff + nb * 32] = v * rs[e];
         }
       }
     };
-    auto finish_act = [&](auto whole_tag) {
-      if (p.act == 0) finish(std::integral_constant<int, 0>{}, whole_tag);
-      else if (p.act == 1) finish(std::integral_constant<int, 1>{}, whole_tag);
-      else finish(std::integral_constant<int, 2>{}, whole_tag);
+    auto finish_act = [&](auto whole_tag, auto add_tag) {
+      if (p.act == 0) finish(std::integral_constant<int, 0>{}, whole_tag, add_tag);
+      else if (p.act == 1) finish(std::integral_constant<int, 1>{}, whole_tag, add_tag);
+      else finish(std::integral_constant<int, 2>{}, whole_tag, add_tag);
     };
-    if (row0 + 32 <= p.M) finish_act(std::true_type{});
-    else finish_act(std::false_type{});
+    auto finish_rows = [&](auto add_tag) {
+      if (row0 + 32 <= p.M) finish_act(std::true_type{}, add_tag);
+      else finish_act(std::false_type{}, add_tag);
+    };
+    if constexpr (KC > 1) {
+      if (p.accumulate) finish_rows(std::true_type{});
+      else finish_rows(std::false_type{});
+    } else {
+      finish_rows(std::false_type{});
+    }
     tile = next;
   }
 }
@@ -491,9 +502,9 @@ int launch_bf16_n(const RowsBf16Args& a, int64_t N, hipStream_t st) {
 }
 
 // Columns per workgroup: the whole weight up to 128 columns, slices of 128 (K <= 128) or 64
-// (K = 256, 384) beyond: what fits LDS as three planes.  (K = 512 would leave 32 columns per
-// workgroup; built and measured, it ran level with the library GEMM, 3.7 ms at 1M x 512 x 512,
-// and is not offered.)
+// (K = 256, 384) beyond: what fits LDS as three planes.  K = 512 would leave 32 columns per
+// workgroup (built and measured: level with the library GEMM, 3.7 ms at 1M x 512 x 512); it
+// runs as two K = 256 launches instead, the second adding to the first one's output.
 int slice_width(int64_t K, int64_t N) {
   if (K == 256 || K == 384) return N % 64 == 0 ? 64 : 0;
   if (N <= 128) return (N % 32 == 0) ? static_cast<int>(N) : 0;
@@ -522,7 +533,9 @@ int launch_n(RowsArgs& a, int64_t K, int64_t N, hipStream_t st) {
 extern "C" {
 
 int spmi_gemm_rows_supported(int64_t K, int64_t N) {
-  if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 384) || N < 32 || N > 4096) return 0;
+  if (N < 32 || N > 4096) return 0;
+  if (K == 512) return slice_width(256, N) != 0;
+  if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 384)) return 0;
   return slice_width(K, N) != 0;
 }
 
@@ -561,7 +574,7 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
                    int64_t ldo, void* stream) {
   SPMI_REQUIRE(spmi_gemm_rows_supported(K, N), SPMI_ERR_UNSUPPORTED,
                "spmi_gemm_rows: K must be 32, 64, 128 (N = 32..128 in steps of 32, or a multiple of 128) "
-               "or 256, 384 (N a multiple of 64) (K=%lld N=%lld)",
+               "or 256, 384, 512 (N a multiple of 64) (K=%lld N=%lld)",
                (long long)K, (long long)N);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gemm_rows: bad M=%lld",
                (long long)M);
@@ -582,7 +595,18 @@ int spmi_gemm_rows(const float* x, int64_t ldx, int64_t M, int64_t K, const void
   if (K == 64) return launch_n<4>(a, K, N, st);
   if (K == 128) return launch_n<8>(a, K, N, st);
   if (K == 256) return launch_n<8, 2>(a, K, N, st);  // wider rows pass in chunks of 128 columns
-  return launch_n<8, 3>(a, K, N, st);
+  if (K == 384) return launch_n<8, 3>(a, K, N, st);
+  // K = 512: columns 0..255 first, plain sums; then columns 256..511 on top of them, with the
+  // bias, the activation and the row scale.  The image is [K-step][plane][k half][N][8], so
+  // the second half's K-steps start 16 * 6 * N chunks of 16 bytes in.
+  RowsArgs lo = a;
+  lo.bias = nullptr; lo.row_scale = nullptr; lo.act = 0;
+  if (int rc = launch_n<8, 2>(lo, 256, N, st)) return rc;
+  RowsArgs hi = a;
+  hi.x = x + 256;
+  hi.wp = a.wp + 16 * 6 * N;
+  hi.accumulate = 1;
+  return launch_n<8, 2>(hi, 256, N, st);
 }
 
 }  // extern "C"

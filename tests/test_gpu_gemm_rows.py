@@ -37,7 +37,7 @@ def test_all_shapes(dev, k, n):
 
 
 @pytest.mark.parametrize("k,n", [(256, 512), (256, 64), (256, 192), (128, 256), (64, 512), (128, 384),
-                                 (384, 128), (384, 64), (384, 256)])
+                                 (384, 128), (384, 64), (384, 256), (512, 512), (512, 64)])
 def test_wide_outputs_in_column_slices(dev, k, n):
     """N > 128 and K = 256, 384 (the 256 -> 512 projection of the
     wide-feature workload; the gate gradients [rows, 3 x 128] times W_ih of a GRU layer's
@@ -57,7 +57,8 @@ def test_wide_outputs_in_column_slices(dev, k, n):
         assert float((got.double().cpu() - want).abs().max()) < 2e-6 * scale, (m, k, n)
     assert not nv.lib().spmi_gemm_rows_supported(256, 96)
     assert not nv.lib().spmi_gemm_rows_supported(128, 160)
-    assert not nv.lib().spmi_gemm_rows_supported(512, 512)
+    assert not nv.lib().spmi_gemm_rows_supported(512, 96)
+    assert not nv.lib().spmi_gemm_rows_supported(640, 128)
 
 
 def test_closer_to_float64_than_the_library(dev):
