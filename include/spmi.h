@@ -339,6 +339,16 @@ int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const 
  * spmi_cell_split_fwd. */
 int spmi_split_f16x3(const float* w /*device [rows, cols]*/, int64_t rows, int64_t cols,
                        void* out /*device 16-bit words, 3*rows*cols*/, void* stream);
+/* The same planes of a matrix given by strides (element (r, c) at w[r * row_stride + c *
+ * col_stride], so a transposed view such as GraphConv's [in, out] weight needs no copy), and,
+ * if amax_bits is not null, the largest |w| for the caller's domain check: the kernel takes
+ * the maximum of *amax_bits (which the caller has set to 0) and the bit patterns of |w|, which
+ * order like the values with NaN on top.  A training loop re-splits every weight after every
+ * optimiser step (the reference's loop, examples/torch/citation_prediction.py:98-101, updates
+ * them all); this keeps that to one launch per weight. */
+int spmi_split_f16x3_strided(const float* w, int64_t rows, int64_t cols, int64_t row_stride,
+                             int64_t col_stride, void* out, uint32_t* amax_bits /*nullable*/,
+                             void* stream);
 int spmi_cell_f16x3_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,
                         const void* ws_hh, const float* b_ih, const float* b_hh, float* h_mem,
                         float* c_mem, const int64_t* ids, int64_t M, int64_t H, float* h_out,

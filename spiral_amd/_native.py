@@ -65,6 +65,7 @@ _SIGNATURES = {
     "spmi_cell_split_fwd": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp]),
     "spmi_split_f16x3": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "spmi_split_f16x3_strided": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "spmi_gemm_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_gemm_rows_bf16_supported": (c_int, [c_i64, c_i64]),
     "spmi_gemm_rows_bf16": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_f32, c_vp, c_i64,

@@ -131,20 +131,34 @@ __device__ __forceinline__ void split_f16x3(float v, _Float16& p0, _Float16& p1,
 // conflicts on every read (SQ_LDS_BANK_CONFLICT was 38 % of the LDS-array cycles).
 template <int MODE>
 __global__ void split_weights_kernel(const float* __restrict__ w, int64_t rows, int64_t cols,
-                                     uint16_t* __restrict__ out) {
+                                     int64_t row_stride, int64_t col_stride,
+                                     uint16_t* __restrict__ out, uint32_t* __restrict__ amax_bits) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  const int64_t n = i / cols, k = i % cols;
+  const bool inside = i < rows * cols;
+  const int64_t n = inside ? i / cols : 0, k = inside ? i % cols : 0;
+  const float v = w[n * row_stride + k * col_stride];
+  if (amax_bits) {
+    // largest |w| as its bit pattern: among non-negative floats the integer order is the
+    // float order, with NaN above infinity, so a NaN weight is reported and not dropped
+    uint32_t b = inside ? (__float_as_uint(v) & 0x7fffffffu) : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = __shfl_xor(b, off);
+      b = o > b ? o : b;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, b);
+  }
+  if (!inside) return;
   uint16_t q0, q1, q2;
   if constexpr (MODE == MODE_F16X3) {
     _Float16 p0, p1, p2;
-    split_f16x3(w[i], p0, p1, p2);
+    split_f16x3(v, p0, p1, p2);
     q0 = __builtin_bit_cast(uint16_t, p0);
     q1 = __builtin_bit_cast(uint16_t, p1);
     q2 = __builtin_bit_cast(uint16_t, p2);
   } else {
     __bf16 hi, mid, lo;
-    split3(w[i], hi, mid, lo);
+    split3(v, hi, mid, lo);
     q0 = __builtin_bit_cast(uint16_t, hi);
     q1 = __builtin_bit_cast(uint16_t, mid);
     q2 = __builtin_bit_cast(uint16_t, lo);
@@ -851,13 +865,15 @@ int launch_split(const SplitArgs& a, hipStream_t st) {
 }
 
 template <int MODE>
-int split_weights(const float* w, int64_t rows, int64_t cols, void* out, void* stream,
-                  const char* name) {
+int split_weights(const float* w, int64_t rows, int64_t cols, int64_t row_stride, int64_t col_stride,
+                  void* out, uint32_t* amax_bits, void* stream, const char* name) {
   SPMI_REQUIRE(rows >= 1 && cols >= 16 && cols % 16 == 0 && w && out, SPMI_ERR_INVALID_ARG,
                "%s: needs rows >= 1, cols a multiple of 16 and non-null pointers", name);
+  SPMI_REQUIRE(row_stride >= 1 && col_stride >= 1, SPMI_ERR_INVALID_ARG, "%s: strides must be positive",
+               name);
   const int64_t n = rows * cols;
-  split_weights_kernel<MODE><<<static_cast<unsigned>((n + 255) / 256), 256, 0,
-                               spmi::as_stream(stream)>>>(w, rows, cols, static_cast<uint16_t*>(out));
+  split_weights_kernel<MODE><<<static_cast<unsigned>((n + 255) / 256), 256, 0, spmi::as_stream(stream)>>>(
+      w, rows, cols, row_stride, col_stride, static_cast<uint16_t*>(out), amax_bits);
   SPMI_CHECK_LAUNCH(name);
   return SPMI_OK;
 }
@@ -904,11 +920,17 @@ int cell_split_fwd(const char* name, int cell, const float* x, int64_t ldx, int6
 extern "C" {
 
 int spmi_split_bf16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
-  return split_weights<MODE_BF16X3>(w, rows, cols, out, stream, "spmi_split_bf16x3");
+  return split_weights<MODE_BF16X3>(w, rows, cols, cols, 1, out, nullptr, stream, "spmi_split_bf16x3");
 }
 
 int spmi_split_f16x3(const float* w, int64_t rows, int64_t cols, void* out, void* stream) {
-  return split_weights<MODE_F16X3>(w, rows, cols, out, stream, "spmi_split_f16x3");
+  return split_weights<MODE_F16X3>(w, rows, cols, cols, 1, out, nullptr, stream, "spmi_split_f16x3");
+}
+
+int spmi_split_f16x3_strided(const float* w, int64_t rows, int64_t cols, int64_t row_stride,
+                             int64_t col_stride, void* out, uint32_t* amax_bits, void* stream) {
+  return split_weights<MODE_F16X3>(w, rows, cols, row_stride, col_stride, out, amax_bits, stream,
+                                   "spmi_split_f16x3_strided");
 }
 
 int spmi_cell_split_fwd(int cell, const float* x, int64_t ldx, int64_t I, const void* ws_ih,

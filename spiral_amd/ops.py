@@ -752,16 +752,21 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_f16x3(w: torch.Tensor) -> torch.Tensor:
+def split_f16x3(w: torch.Tensor, amax_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The weight matrix [rows, cols] as the planes fp16(w), fp16(w/64), fp16((w - fp16(w))*64),
     tiled [cols/16, 3, 2, rows, 8] (K-step, plane, half of the K-step, row, k) for the
-    three-product kernels."""
-    w = w.detach().contiguous()
+    three-product kernels.  `w` may be any 2-D view with positive strides (a `.t()` view is read
+    through its strides, not copied).  `amax_slot`: a zeroed int32 device scalar that receives
+    the bit pattern of the largest |w| (NaN included) from the same launch."""
+    w = w.detach()
+    if w.dim() != 2 or w.dtype != torch.float32 or min(w.stride()) < 1:
+        w = w.contiguous().float()
     rows, cols = w.shape
     out = torch.empty(cols // 16, 3, 2, rows, 8, dtype=torch.float16, device=w.device)
     with torch.cuda.device(w.device):
-        nv.check(nv.lib().spmi_split_f16x3(nv.ptr(w), rows, cols, nv.ptr(out), nv.stream()),
-                 "spmi_split_f16x3")
+        nv.check(nv.lib().spmi_split_f16x3_strided(
+            nv.ptr(w), rows, cols, w.stride(0), w.stride(1), nv.ptr(out), nv.ptr(amax_slot),
+            nv.stream()), "spmi_split_f16x3_strided")
     return out
 
 
@@ -812,15 +817,31 @@ class WeightCacheHooks:
         invalidate_weight_caches()
 
 
+_amax_pools: dict = {}
+
+
+def _amax_slot(device: torch.device) -> torch.Tensor:
+    """A zeroed int32 device scalar for one domain check: slots come from blocks of 256 that are
+    zeroed in one fill, so a check costs no launch of its own for that."""
+    key = (device.type, device.index)
+    pool = _amax_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _amax_pools[key] = [torch.zeros(256, dtype=torch.int32, device=device), 0]
+    slot = pool[0][pool[1]: pool[1] + 1]
+    pool[1] += 1
+    return slot
+
+
 class _DomainCheck:
     """max |w| of a weight on its way to pinned host memory, so that the domain check of the
     fp16-plane kernels never makes the host wait for the device: the value is looked at the
-    first time the planes are used again after the copy has landed."""
+    first time the planes are used again after the copy has landed.  `slot`: the scalar the
+    split kernel left the bit pattern of max |w| in."""
 
-    def __init__(self, src: torch.Tensor, limit: float):
+    def __init__(self, slot: torch.Tensor, limit: float):
         self.limit = limit
         self.host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-        self.host.copy_(torch.linalg.vector_norm(src.float(), ord=float("inf")).reshape(1), non_blocking=True)
+        self.host.copy_(slot.view(torch.float32), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
@@ -853,11 +874,16 @@ def weight_planes(w: torch.Tensor, kind: str = "f16x3", transposed: bool = False
         if slot[1] == key:
             return slot[2]
     src = w.detach().t() if transposed else w.detach()
-    planes = split_f16x3(src) if kind == "f16x3" else split_bf16x3(src)
     check = None
-    if limit is not None and kind == "f16x3" and src.numel():
+    if kind != "f16x3":
+        planes = split_bf16x3(src)
+    elif limit is not None and src.numel():
         with torch.cuda.device(w.device):
-            check = _DomainCheck(src, limit)
+            slot = _amax_slot(w.device)
+            planes = split_f16x3(src, slot)
+            check = _DomainCheck(slot, limit)
+    else:
+        planes = split_f16x3(src)
     ref = weakref.ref(w, lambda _r, k=slot_id: _plane_cache.pop(k, None))
     _plane_cache[slot_id] = (ref, key, planes, check)
     return planes

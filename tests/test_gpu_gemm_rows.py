@@ -294,3 +294,25 @@ def test_rows_stored_as_bfloat16(dev, k, n, out_dtype):
         else:
             # one rounding to bfloat16 on top of the float32 sum's own 1e-5 of the scale
             assert bool((err <= want.abs() * 2.0 ** -8 + 1e-5 * float(want.abs().max())).all())
+
+
+def test_strided_split_and_largest_magnitude_in_one_launch(dev):
+    """Planes of a transposed view read through its strides equal the planes of a contiguous
+    copy bit for bit, and the same launch leaves the bit pattern of max |w| (NaN on top) in
+    the caller's zeroed slot."""
+    gen = torch.Generator().manual_seed(77)
+    w = (torch.randn(96, 160, generator=gen) * 3).to(dev)      # [in, out] as GraphConv keeps it
+    slot = torch.zeros(1, dtype=torch.int32, device=dev)
+    got = ops.split_f16x3(w.t(), slot)
+    want = ops.split_f16x3(w.t().contiguous())
+    assert got.shape == want.shape == (96 // 16, 3, 2, 160, 8)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert float(slot.view(torch.float32)) == float(w.abs().max())
+    wide = torch.randn(64, 200, generator=gen).to(dev)
+    view = wide[:, 8:8 + 128]                                    # row stride 200, offset 8
+    assert torch.equal(ops.split_f16x3(view).view(torch.int16),
+                       ops.split_f16x3(view.contiguous()).view(torch.int16))
+    w[5, 7] = float("nan")
+    slot.zero_()
+    ops.split_f16x3(w.t(), slot)
+    assert torch.isnan(slot.view(torch.float32)).item()
