@@ -543,7 +543,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run(args.warmup + i, True)
+        # stage boundaries (five event records, each a packet of its own in the queue) on every
+        # fourth step; the aggregation launches are timed on all of them
+        run(args.warmup + i, args.per_step or i % 4 == 0)
     drain()  # ... and ends with it empty: exactly `steps` whole snapshots inside
     barrier()
     elapsed = time.perf_counter() - t0
