@@ -118,8 +118,10 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   const int lh = lane >> 5;
   const int64_t n_tiles = (p.M + 31) / 32;
   const int64_t stride = static_cast<int64_t>(n_groups) * NW;
-  int64_t tile = static_cast<int64_t>(group) * NW + wave;
-  if (tile >= n_tiles) return;
+  // Tiles are walked from the last row down: the rows a producer (the aggregation of the layer
+  // before) wrote last are the ones the memory-side cache still holds when this kernel starts.
+  int64_t tile = n_tiles - 1 - (static_cast<int64_t>(group) * NW + wave);
+  if (tile < 0) return;
 
   float bias[NB];
 #pragma unroll
@@ -149,10 +151,10 @@ __global__ __launch_bounds__(KT > 8 ? 256 : 512, KT > 8 ? 1 : 2) void gemm_rows_
   }
   const int b_rd = (lh * N + lr) * 16;  // [plane][k half][n][8]: 512 contiguous bytes per half
 
-  while (tile < n_tiles) {
-    const int64_t next = tile + stride;
+  while (tile >= 0) {
+    const int64_t next = tile - stride;
     // the last iteration re-reads its own tile: valid memory, nothing is done with it
-    const float* src_next = row_ptr(next < n_tiles ? next : tile);
+    const float* src_next = row_ptr(next >= 0 ? next : tile);
     const float* src_own = row_ptr(tile);
 
     f32x16 acc[NB];

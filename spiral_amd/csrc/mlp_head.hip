@@ -295,8 +295,10 @@ __global__ __launch_bounds__(64 * (KC > 1 ? 2 : 1) * kMfmaWaves, 2) void mlp_hea
 
   const int64_t n_tiles = (p.M + 31) / 32;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * NW;
-  int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave;
-  if (tile >= n_tiles) return;  // no barrier below
+  // Tiles are walked from the last row down: what the producer of x wrote last is what the
+  // memory-side cache still holds when this kernel starts.
+  int64_t tile = n_tiles - 1 - (static_cast<int64_t>(blockIdx.x) * NW + wave);
+  if (tile < 0) return;  // no barrier below
 
   float b1[16];
 #pragma unroll
@@ -319,11 +321,11 @@ __global__ __launch_bounds__(64 * (KC > 1 ? 2 : 1) * kMfmaWaves, 2) void mlp_hea
   }
   const int frag = lh * 512 + lr * 16;  // this lane's 16 bytes inside a plane [k half][unit][8]
 
-  while (tile < n_tiles) {
-    const int64_t next = tile + stride;
+  while (tile >= 0) {
+    const int64_t next = tile - stride;
     int64_t r_own = tile * 32 + lr;
     r_own = r_own < p.M ? r_own : p.M - 1;
-    int64_t r_next = (next < n_tiles ? next : tile) * 32 + lr;  // last pass re-reads its own tile
+    int64_t r_next = (next >= 0 ? next : tile) * 32 + lr;  // last pass re-reads its own tile
     r_next = r_next < p.M ? r_next : p.M - 1;
 
     f32x16 cur;
