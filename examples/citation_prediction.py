@@ -86,7 +86,6 @@ def main():
     n_nodes = last.num_nodes()
     in_dim = last.num_node_features()
     model = build_model(args, in_dim, n_nodes).to(dev)
-    model.decoder.to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     first = min(5, n_snapshot - 4)

@@ -71,8 +71,8 @@ def test_training_loop_matches_cpu_restatement(dev, kind):
     rnn = cls(16, 10, n_nodes, 2, MLP(10, [10, 20, 10, 5], dropout=0.0))
     model = assembler(gnn, rnn)
     ref = CpuReference(model, kind, n_nodes)
-    model.to(dev)
-    model.decoder.to(dev)
+    model.to(dev)  # the assembler moves the decoder's node memories too
+    assert model.decoder.memory_h.memory.device.type == "cuda"
     model.train()
     ref.rnn.train()
     ref.mlp.train()
