@@ -20,3 +20,48 @@ def test_example_runs(monkeypatch, capsys, gnn, rnn):
     runpy.run_path(SCRIPT, run_name="__main__")
     out = capsys.readouterr().out
     assert "epoch 0: train loss" in out and "nan" not in out.lower()
+
+
+def test_reference_script_idioms():
+    """The calls of examples/torch/citation_prediction.py:34-103 as written there, package name
+    swapped and `.to("cuda")` on the assembled model: the id tensor is built on the CPU
+    (`torch.arange(n)`, :96), the optimiser takes a parameter-group list (:85), GraphSage
+    keeps its default depth (:71)."""
+    import torch
+    import torch.nn.functional as F
+
+    sys.path.insert(0, os.path.dirname(SCRIPT))
+    try:
+        from citation_prediction import synthetic_citation_data
+    finally:
+        sys.path.pop(0)
+    from spiral_amd.automl.model_assembler import assembler
+    from spiral_amd.dtdg.dataloader import preprocess_citation_graph
+    from spiral_amd.dtdg.models.decoder.sequentialDecoders import GRU
+    from spiral_amd.dtdg.models.decoder.simpleDecoders import MLP
+    from spiral_amd.dtdg.models.encoder.implicitTimeEncoder.staticGraphEncoder import GCN, GraphSage
+
+    this_graph = preprocess_citation_graph(synthetic_citation_data(3000, 20000, 10, 8), "node_year")
+    n_snapshot = len(this_graph)
+    n_nodes = this_graph.dispatcher(n_snapshot - 1)[0].observation.num_nodes()
+    this_snapshot, _ = this_graph.dispatcher(5)
+    in_dim = this_snapshot.num_node_features()
+    for gnn in (GCN(2, in_dim, 32, activation=F.leaky_relu, allow_zero_in_degree=True, dropout=0.2),
+                GraphSage("gcn", in_dim, 32, activation=F.leaky_relu)):
+        rnn = GRU(32, 10, n_nodes, 2, MLP(10, [10, 20, 10, 5]))
+        this_model = assembler(gnn, rnn).to("cuda")
+        loss_fn = torch.nn.MSELoss().to("cuda")
+        optimizer = torch.optim.Adam([{"params": this_model.parameters()}], lr=1e-3)
+        this_model.decoder.reset_memory_state()
+        for t in range(5, n_snapshot - 2):
+            this_model.train()
+            optimizer.zero_grad()
+            this_snapshot, node_samples = this_graph.dispatcher(t)
+            next_snapshot, _ = this_graph.dispatcher(t + 1)
+            node_samples = torch.arange(this_snapshot.num_nodes())
+            predict = this_model.forward((this_snapshot, node_samples))
+            label = next_snapshot.node_feature()[: this_snapshot.num_nodes(), -1].float()
+            loss = loss_fn(predict.squeeze(), label)
+            loss.backward()
+            optimizer.step()
+        assert torch.isfinite(loss).item()
