@@ -427,6 +427,30 @@ def citation_tables_loops(graph_data, node_time: str, edges_key="edge_index", no
     return edges, nodes[:, 1:], timestamps
 
 
+def prepare_citation_task(edges, nodes, n_timestamps, start_t=1, validating_snapshots=5,
+                          minimum_citation=5):
+    """spiro/automl/tf/prepare_dataset.py:97-122 on the numpy container: (targets, labels),
+    dicts over t.  Parity unpinned: the reference's only test of it
+    (tests/automl/batch_generator_test.py) counts batches and runs on TensorFlow."""
+    feat = lambda t: citation_dispatch(edges, nodes, n_timestamps, t)
+    targets, labels = {}, {}
+    times, v = n_timestamps, validating_snapshots
+    for t in range(start_t, times - v - 1):
+        n = feat(t)[2]
+        later = feat(t + v)[3]
+        target = np.where(later[np.arange(n), -1] > minimum_citation)[0]
+        new_citation = feat(t + 1)[3][:n, -1]
+        targets[t] = target.astype(np.int32)
+        labels[t] = new_citation[target]
+    target = targets[times - 2 - v]
+    for t in range(times - v - 1, times - 1):
+        n = feat(t)[2]
+        new_citation = feat(t + 1)[3][:n, -1]
+        targets[t] = target
+        labels[t] = new_citation[target]
+    return targets, labels
+
+
 # ----------------------------------------------------------------------------- recurrent cells
 def _sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)

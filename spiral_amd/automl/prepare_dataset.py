@@ -1,5 +1,5 @@
-"""Edge-task (link prediction) preparation; API of spiro/automl/tf/prepare_dataset.py:37-94,
-which the reference only ships for its TensorFlow backend.  The sampling itself is
+"""Task preparation: edge task (link prediction, spiro/automl/tf/prepare_dataset.py:37-94) and
+citation task (:97-122), which the reference only ships for its TensorFlow backend.  The sampling itself is
 host-side numpy with the same draws (np.random) as the reference; successor lists come
 from one copy of the snapshot's by-source CSR instead of a graph query per node."""
 from typing import List, Optional, Tuple
@@ -9,7 +9,7 @@ import torch
 
 from spiral_amd.core.dataio import neg_sampling
 from spiral_amd.core.errors import DimensionError
-from spiral_amd.dtdg.types import Snapshot, VEInvariantDTDG
+from spiral_amd.dtdg.types import CitationGraph, Snapshot, VEInvariantDTDG
 
 TARGET = "target"
 LABEL = "label"
@@ -69,3 +69,38 @@ def prepare_edge_task(dgraph: VEInvariantDTDG, num_postive: int, num_negative: O
         dgraph.time_data[TARGET][t] = torch.from_numpy(np.array(pos + neg).astype("int64"))
         labels = np.concatenate((np.ones(len(pos)), np.zeros(len(neg)) + float(negative_label)))
         dgraph.time_data[LABEL][t] = torch.from_numpy(labels)
+
+
+def prepare_citation_task(dgraph: CitationGraph, start_t: int = 1, validating_snapshots: int = 5,
+                          minimum_citation: int = 5) -> None:
+    """Fill dgraph.time_data['target'|'label'][t] for the citation-prediction task
+    (spiro/automl/tf/prepare_dataset.py:97-122).  For t in [start_t, T - V - 1): target = the
+    nodes of snapshot t that have more than `minimum_citation` citations V snapshots later,
+    label = their citation count in snapshot t + 1.  The last V snapshots before the final one
+    keep the target set of snapshot T - V - 2 with their own labels.  The citation count is the
+    last feature column of a CitationGraph snapshot.  Tensors stay on the graph's device
+    (targets int32, labels float32); the loop runs over snapshots only."""
+    times, v = len(dgraph), validating_snapshots
+    dgraph.time_data[TARGET] = {}
+    dgraph.time_data[LABEL] = {}
+
+    def new_citation(t: int, n: int) -> torch.Tensor:
+        nxt, _ = dgraph.dispatcher(t + 1)
+        return nxt.node_feature()[:n, -1]
+
+    for t in range(start_t, times - v - 1):
+        this_snapshot, node_samples = dgraph.dispatcher(t)
+        later, _ = dgraph.dispatcher(t + v)
+        counts = later.node_feature()[:, -1].index_select(0, node_samples.to(torch.int64))
+        target = torch.nonzero(counts > minimum_citation).reshape(-1)
+        dgraph.time_data[TARGET][t] = target.to(torch.int32)
+        dgraph.time_data[LABEL][t] = new_citation(t, this_snapshot.num_nodes()).index_select(0, target)
+    if times - 2 - v not in dgraph.time_data[TARGET]:
+        raise DimensionError(f"{times} snapshots leave no training snapshot in front of the last "
+                             f"{v} + 1 (start_t = {start_t})")
+    target = dgraph.time_data[TARGET][times - 2 - v]
+    for t in range(times - v - 1, times - 1):
+        this_snapshot, _ = dgraph.dispatcher(t)
+        dgraph.time_data[TARGET][t] = target
+        dgraph.time_data[LABEL][t] = new_citation(t, this_snapshot.num_nodes()).index_select(
+            0, target.to(torch.int64))

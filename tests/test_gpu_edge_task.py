@@ -143,3 +143,34 @@ def test_edge_head_matches_oracle_and_torch_restatement(dev, kind):
 
     with pytest.raises(DimensionError):
         head((out[:, 0, :].detach(), torch.zeros(2, 2, 2, dtype=torch.long)))
+
+
+def test_prepare_citation_task_against_the_loop_form(dev):
+    """Targets and labels of the citation task (spiro/automl/tf/prepare_dataset.py:97-122) for
+    the container of the reference's own fixture (tests/automl/batch_generator_test.py:21-23,
+    validating_snapshots=1, minimum_citation=0) and for a random table."""
+    from spiral_amd.automl.prepare_dataset import LABEL, TARGET, prepare_citation_task
+    from spiral_amd.dtdg.types import CitationGraph
+
+    edges = np.array([[0, 0, 1], [0, 0, 2], [1, 3, 0], [2, 4, 1], [2, 4, 2]])
+    nodes = np.array([[0, 0], [0, 1], [0, 2], [1, 3], [2, 4], [3, 9]])
+    times = np.array([2006, 2007, 2008, 2009])
+    cases = [(edges, nodes, times, dict(start_t=1, validating_snapshots=1, minimum_citation=0))]
+    rng = np.random.default_rng(4)
+    n, e, steps = 400, 5000, 12
+    node_t = np.sort(rng.integers(0, steps, n))
+    a, b = rng.integers(0, n, e), rng.integers(0, n, e)
+    s, d = np.maximum(a, b), np.minimum(a, b)
+    big_e = np.stack([node_t[s], s, d], 1)[np.argsort(node_t[s], kind="stable")]
+    big_n = np.hstack([node_t[:, None], rng.integers(0, 5, (n, 3))])
+    cases.append((big_e, big_n, np.arange(steps), dict(start_t=2, validating_snapshots=3, minimum_citation=4)))
+    for ed, no, ti, kw in cases:
+        graph = CitationGraph(ed.astype(np.float64), no.astype(np.float64), ti, device=dev)
+        prepare_citation_task(graph, **kw)
+        want_t, want_l = orc.prepare_citation_task(ed.astype(np.float64), no.astype(np.float64), len(ti), **kw)
+        assert sorted(graph.time_data[TARGET]) == sorted(want_t)
+        for t in want_t:
+            got_t, got_l = graph.time_data[TARGET][t], graph.time_data[LABEL][t]
+            assert got_t.dtype == torch.int32 and got_t.device.type == "cuda"
+            np.testing.assert_array_equal(got_t.cpu().numpy(), want_t[t])
+            np.testing.assert_array_equal(got_l.cpu().numpy(), want_l[t].astype(np.float32))
