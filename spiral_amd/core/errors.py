@@ -19,3 +19,7 @@ DGLError = GraphError
 class BackendNotSupportedError(Exception):
     """A backend other than PyTorch was asked for (spiro/core/errors.py; the TensorFlow
     backend of the reference is not part of this library)."""
+
+
+class ValueError(Exception):  # noqa: A001  (the reference's name, spiro/core/errors.py:42)
+    """The package's own value error; shadows the builtin inside this module only."""

@@ -15,3 +15,22 @@ def get_anchor_position(arr_to_search: ndarray, anchors) -> ndarray:
     arr = np.asarray(arr_to_search)
     ends = np.searchsorted(arr, np.asarray(list(anchors)), side="left")[1:]
     return np.concatenate([ends, [arr.shape[0]]]).astype(np.int64)
+
+
+def _get_backend() -> str:
+    """The backend in force (spiro/core/utils.py:58-60)."""
+    from spiral_amd.core.config import get_backend
+
+    return get_backend()
+
+
+def printProgressBar(iteration, total, prefix="", suffix="", decimals=1, length=100, fill="█",
+                     printEnd="\r") -> None:
+    """One line of a terminal progress bar, redrawn in place (spiro/core/utils.py:64-83):
+    `prefix |####----| 42.0% suffix`; a newline once `iteration` reaches `total`."""
+    done = iteration / float(total)
+    cells = int(length * iteration // total)
+    print(f"\r{prefix} |{fill * cells}{'-' * (length - cells)}| {100 * done:.{decimals}f}% {suffix}",
+          end=printEnd)
+    if iteration == total:
+        print()

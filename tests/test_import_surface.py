@@ -41,3 +41,21 @@ def test_backend_selection_as_the_reference_tests_it(monkeypatch):
     import spiral_amd.core.backend_config.torch as by_code
     importlib.reload(by_code)
     assert os.environ["DGLBACKEND"] == PYTORCH
+
+
+def test_small_helpers_under_the_reference_names(capsys):
+    import numpy as np
+    import torch
+
+    from spiral_amd.core import errors
+    from spiral_amd.core.torch_functions import _to_tensor, nt_layers_list, reshape_tensor
+    from spiral_amd.core.utils import _get_backend, printProgressBar
+
+    assert _get_backend() == "pytorch"
+    assert torch.equal(reshape_tensor(_to_tensor(np.arange(6)), [2, 3]), torch.arange(6).reshape(2, 3))
+    assert isinstance(nt_layers_list(), torch.nn.ModuleList)
+    assert issubclass(errors.ValueError, Exception) and errors.ValueError is not ValueError
+    printProgressBar(1, 4, prefix="p", suffix="s", length=8)
+    printProgressBar(4, 4, prefix="p", suffix="s", length=8)
+    out = capsys.readouterr().out
+    assert "p |██------| 25.0% s" in out and "p |████████| 100.0% s" in out and out.endswith("\n")
