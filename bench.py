@@ -49,6 +49,7 @@ from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP  # noqa: E402
 from spiral_amd.dtdg.types import identity_ids  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak of the part (no sparsity)
 HEAD_DIMS = [10, 20, 10, 5]  # the MLP of examples/torch/citation_prediction.py:73
 CPU_SAMPLE_DIV = 4      # the CPU baseline runs a snapshot of 1/4 of the nodes and edges
 
@@ -584,6 +585,20 @@ def main():
         stages["csr_build_roofline"] = {"bound": "hbm", "algorithmic_bytes": build_bytes, "achieved": gbs,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                         "covers": "COO->CSR by destination, out-degrees, both normalisers, hub-row plan"}
+
+    if ("recurrent_ms" in stages and stages["recurrent_ms"] > 0 and kind == "gcn_gru" and not train
+            and ops.CELL_GEMM == "f16x3"):
+        # the recurrent stage against the matrix cores: 2 GRU layers, each 2*N*(I+H)*3H flops as
+        # fp32 arithmetic, issued as three fp16 plane products per term (the stage also holds the
+        # head: HBM-bound, 2-3 % of the matrix work's time)
+        hid, rh = w["hidden"], w["rnn_hidden"]
+        alg = 2.0 * n_rows * ((hid + rh) + (rh + rh)) * 3 * rh
+        tfs = 3.0 * alg / (stages["recurrent_ms"] * 1e-3) / 1e12
+        stages["recurrent_roofline"] = {"bound": "mfma", "algorithmic_flops": alg, "matrix_flops": 3.0 * alg,
+                                        "achieved": tfs, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": tfs / MFMA_F16_PEAK_TFLOPS,
+                                        "covers": "2 GRU layers (fp32 results from three fp16 plane products "
+                                                  "per term: matrix_flops = 3 x algorithmic) + MLP head"}
 
     train_ms = None
     if (world == 1 and not train and kind == "gcn_gru" and not args.no_train_probe and rank == 0):
