@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / 64;
-constexpr int kUnroll = 8;  // source rows in flight per wave
+constexpr int kUnroll = 16;  // source rows in flight per wave
 
 template <int VEC>
 struct VecOf;
