@@ -117,6 +117,22 @@ def _plan(indptr: torch.Tensor, n_rows: int, e: int, meta: torch.Tensor, heavy_t
     return heavy_rows, heavy_ptr
 
 
+_meta_pools: Dict = {}
+
+
+def _zeroed_meta(device: torch.device) -> torch.Tensor:
+    """int32[3] (status, n_heavy, n_chunks) of one build, zeroed: a slice of a block of 256 that
+    is zeroed with one fill, so a build launches no fill of its own.  A slice is handed out
+    once; a block lives for as long as one of its slices does."""
+    key = (device.type, device.index)
+    pool = _meta_pools.get(key)
+    if pool is None or pool[1] >= 256:
+        pool = _meta_pools[key] = [torch.zeros(256, 4, dtype=torch.int32, device=device), 0]
+    meta = pool[0][pool[1], :3]
+    pool[1] += 1
+    return meta
+
+
 def _fetch_meta(meta: torch.Tensor):
     """Queue the copy of a build's (status, n_heavy, n_chunks) to pinned host memory and an
     event behind it; the device tensor rides along so its memory outlives the copy."""
@@ -143,7 +159,7 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
         indptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
         indices = torch.empty(e, dtype=torch.int32, device=dev)
         eid = torch.empty(e, dtype=torch.int32, device=dev) if want_eid else None
-        meta = torch.zeros(3, dtype=torch.int32, device=dev)  # status, n_heavy, n_chunks
+        meta = _zeroed_meta(dev)  # status, n_heavy, n_chunks
         ws_bytes = lib.spmi_coo_to_csr_workspace_bytes(e, n_key)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         nv.check(lib.spmi_coo_to_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
@@ -182,7 +198,7 @@ class CumulativeCSR:
             indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
             indices = torch.empty(e_cut, dtype=torch.int32, device=dev)
             eid = torch.empty(e_cut, dtype=torch.int32, device=dev) if want_eid else None
-            meta = torch.zeros(3, dtype=torch.int32, device=dev)
+            meta = _zeroed_meta(dev)
             ws_bytes = lib.spmi_csr_prefix_workspace_bytes(n_rows)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             nv.check(lib.spmi_csr_prefix(nv.ptr(full.indptr), nv.ptr(full.indices), nv.ptr(full.eid),
