@@ -375,6 +375,59 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
   }
 }
 
+// The same with 16-byte accesses: a thread holds four columns, sixteen threads cover the 64
+// columns of the block and a wave four rows per access, four accesses in flight.
+__global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* __restrict__ gY,
+                                                                   const float* __restrict__ Y,
+                                                                   int64_t M, int F, int64_t ld,
+                                                                   int act, float slope,
+                                                                   float* __restrict__ gP,
+                                                                   float* __restrict__ gb) {
+  __shared__ float4 s_col[16][16];
+  const int cg = threadIdx.x & 15;   // column group: columns f .. f + 3
+  const int rl = threadIdx.x >> 4;   // 0 .. 15: rows rl, rl + 16, ...
+  const int f = blockIdx.y * 64 + 4 * cg;
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBwdRowsPerBlock;
+  const int64_t row1 = row0 + kBwdRowsPerBlock < M ? row0 + kBwdRowsPerBlock : M;
+  const float neg = (act == SPMI_ACT_RELU) ? 0.0f : slope;
+  float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f < F) {
+    constexpr int U = 4;
+    for (int64_t r = row0 + rl; r < row1; r += 16 * U) {
+      float4 g[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r + 16 * u < row1 ? r + 16 * u : r;  // past the slab: re-read, not stored
+        g[u] = *reinterpret_cast<const float4*>(gY + rr * ld + f);
+        if (act != SPMI_ACT_NONE) y[u] = *reinterpret_cast<const float4*>(Y + rr * ld + f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r + 16 * u >= row1) break;
+        if (act != SPMI_ACT_NONE) {
+          g[u].x = y[u].x > 0.0f ? g[u].x : g[u].x * neg;
+          g[u].y = y[u].y > 0.0f ? g[u].y : g[u].y * neg;
+          g[u].z = y[u].z > 0.0f ? g[u].z : g[u].z * neg;
+          g[u].w = y[u].w > 0.0f ? g[u].w : g[u].w * neg;
+        }
+        *reinterpret_cast<float4*>(gP + (r + 16 * u) * F + f) = g[u];
+        col.x += g[u].x; col.y += g[u].y; col.z += g[u].z; col.w += g[u].w;
+      }
+    }
+  }
+  if (gb) {
+    s_col[rl][cg] = col;
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.y * 64 + static_cast<int>(threadIdx.x) < F) {
+      const float* flat = reinterpret_cast<const float*>(&s_col[0][0]);  // [16 rows][64 columns]
+      float sum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += flat[q * 64 + threadIdx.x];
+      atomicAdd(&gb[blockIdx.y * 64 + threadIdx.x], sum);
+    }
+  }
+}
+
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 template <int VEC, typename XT, typename YT>
@@ -572,8 +625,13 @@ int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int
                "spmi_act_bias_bwd: null pointer");
   const unsigned gx = static_cast<unsigned>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);
   const unsigned gy = static_cast<unsigned>((F + 63) / 64);
-  act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
-      gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
+  const bool v4 = F % 4 == 0 && ld % 4 == 0 && aligned(gY, 16) && aligned(gP, 16) && (!Y || aligned(Y, 16));
+  if (v4)
+    act_bias_bwd_v4_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
+  else
+    act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
   SPMI_CHECK_LAUNCH("act_bias_bwd");
   return SPMI_OK;
 }

@@ -121,3 +121,27 @@ def test_bf16_feature_storage(dev, f, out_bf16):
     err = np.abs(got.float().cpu().numpy() - want)
     bound = RTOL * scale + (2.0 ** -8) * np.abs(want) * out_bf16
     assert (err <= bound).all(), f"worst excess {(err - bound).max():.3e}"
+
+
+@pytest.mark.parametrize("m,f,pad", [(1, 128, 0), (1000, 128, 0), (5003, 64, 32), (777, 129, 0), (2049, 6, 2),
+                                     (40_000, 256, 0)])
+@pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
+def test_activation_and_bias_backward(dev, m, f, pad, act):
+    """gP = gY * act'(Y) and the column sums of gP (the bias gradient), with 16-byte accesses
+    where widths and alignment allow and scalar ones elsewhere; strided inputs."""
+    from spiral_amd import ops
+
+    gen = torch.Generator().manual_seed(m + f)
+    wide_g = torch.randn(m, f + pad, generator=gen).to(dev)
+    wide_y = torch.randn(m, f + pad, generator=gen).to(dev)
+    g_y, y = wide_g[:, :f], wide_y[:, :f]
+    g_p, g_b = ops._act_bias_bwd(g_y, y, act, 0.01, True)
+    if act is None:
+        want = g_y
+    elif act == "relu":
+        want = torch.where(y > 0, g_y, torch.zeros_like(g_y))
+    else:
+        want = torch.where(y > 0, g_y, g_y * 0.01)
+    assert torch.equal(g_p, want.contiguous())
+    ref_b = want.double().sum(0)
+    assert float((g_b.double() - ref_b).abs().max()) <= 1e-5 * max(float(ref_b.abs().max()), 1.0)
