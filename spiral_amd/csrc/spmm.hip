@@ -88,7 +88,9 @@ template <int VEC, typename T>
 __device__ __forceinline__ void store_row(T* p, typename VecOf<VEC>::type v) {
   using V = typename VecOf<VEC>::type;
   if constexpr (sizeof(T) == 4) {
-    *reinterpret_cast<V*>(p) = v;
+    // streamed out: the output rows are not read again by this launch and should not push
+    // the gathered rows out of the caches (step 4.007 -> 3.997 ms, 0.893 -> 0.897 of the peak)
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
   } else if constexpr (VEC == 1) {
     *p = static_cast<T>(v);
   } else {
