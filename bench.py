@@ -13,8 +13,11 @@ ranks together).  The fused aggregation launches inside the timed region are tim
 HIP events on their stream; `roofline` prices them against the HBM peak with the gather
 model  B = E*(F*4+4) + (N+1)*4 + 2*N*4 + N*F*4 + F*4  bytes per launch.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Without a launcher's environment (no RANK / WORLD_SIZE) and N > 1 the first form starts its own
+N rank processes (`self_launch`); under torch.distributed.run every process is a rank.
 
 N>1: the snapshot is row-partitioned over the ranks (destination blocks cut at equal edge
 counts); the exchange of source rows (RCCL all-to-all of the rows each rank's edges name) is
@@ -31,16 +34,91 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-import torch.nn.functional as F
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from spiral_amd import graph as G
+
+def _gpus_on_command_line(argv) -> int:
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def self_launch(argv) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: start the N rank processes
+    from here, one per GPU, and hand back rank 0's JSON line.
+
+    The ranks are fresh interpreters (fork + exec of this file), started before this process has
+    imported torch or loaded the HIP library, so nothing that has touched a GPU is ever replaced
+    or forked.  Rank 0's stdout is passed through; the other ranks' stdout goes to stderr, so
+    stdout carries one JSON line as in the single-process case.  The exit status is the first
+    non-zero status of a rank (a rank that dies takes the others down after a grace period:
+    they would otherwise sit in a collective until its timeout)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    n = _gpus_on_command_line(argv)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPMI_BENCH_LAUNCHED_BY=str(os.getpid()))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+
+    def forward_signal(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, forward_signal)
+
+    def pump():  # rank 0's lines as they come
+        for raw in procs[0].stdout:
+            sys.stdout.write(raw.decode(errors="replace"))
+            sys.stdout.flush()
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    grace = float(os.environ.get("SPMI_BENCH_LAUNCH_GRACE_S", "20"))
+    status, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            code = p.poll()
+            if code not in (None, 0) and status == 0:
+                status, failed_at = code, time.monotonic()
+                print(f"bench.py launcher: rank {r} exited with status {code}", file=sys.stderr, flush=True)
+        if failed_at is not None and time.monotonic() - failed_at > grace:
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for p in procs:
+        if p.returncode != 0 and status == 0:
+            status = p.returncode
+    return status if status >= 0 else 128 - status
+
+
+if (__name__ == "__main__" and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ
+        and _gpus_on_command_line(sys.argv[1:]) > 1):
+    sys.exit(self_launch(sys.argv[1:]))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from spiral_amd import graph as G  # noqa: E402
 from spiral_amd import ops  # noqa: E402
 from spiral_amd import parallel as par  # noqa: E402
 from spiral_amd.core.types import GraphConv  # noqa: E402
@@ -135,6 +213,7 @@ def _stage_collectives_through_host():
         return call
 
     dist.all_to_all_single = staged(dist.all_to_all_single, 0)
+    dist.all_gather_into_tensor = staged(dist.all_gather_into_tensor, 0)
     dist.all_reduce = staged(dist.all_reduce, 0)
     dist.broadcast = staged(dist.broadcast, 0)
 
@@ -310,7 +389,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         "(it launches its own ranks) or under torch.distributed.run with N processes")
+    if os.environ.get("SPMI_BENCH_LAUNCH_CHECK") == "1":
+        # the launcher's plumbing alone, without a GPU: rendezvous, one collective, rank 0's line
+        dist.init_process_group("gloo")
+        total = torch.tensor([rank + 1])
+        dist.all_reduce(total)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world": world, "rank_sum": int(total),
+                              "launched_by_bench": "SPMI_BENCH_LAUNCHED_BY" in os.environ}), flush=True)
+        dist.destroy_process_group()
+        if os.environ.get("SPMI_BENCH_LAUNCH_CHECK_FAIL_RANK") == str(rank):
+            raise SystemExit(7)
+        return
     # SPMI_BENCH_REHEARSE=1: every rank on cuda:0 over gloo, to walk the multi-rank code path
     # on a one-GPU box (not a measurement; RCCL needs one device per rank).
     rehearse = os.environ.get("SPMI_BENCH_REHEARSE") == "1"
@@ -381,14 +473,45 @@ def main():
         x_full = torch.cat(xs)
         del xs
 
-    stage_names = ("csr_build", "conv1", "conv2", "recurrent")
+    # Stage boundaries: a list of (name, event) per recorded step; "name" ends at its event.
     stage_events = []
+    plan_stats = []   # per sharded snapshot of the timed region: (edges, rows received, rows sent)
+
+    class Marks:
+        def __init__(self, record):
+            self.ev = [] if record else None
+            self("start")
+
+        def __call__(self, name):
+            if self.ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.ev.append((name, e))
+
+        def done(self):
+            if self.ev is not None:
+                stage_events.append(self.ev)
+
+    def sharded(src, dst, mark, **kw):
+        """This rank's block of a snapshot with everything a layer needs queued: the exchange
+        plan (one host round trip), the CSR(s) of the block, both normalisers (the source one
+        costs one small all-to-all: out-degrees are summed by the rows' owners)."""
+        shard = par.ShardedSnapshot(src, dst, part, stages=n_stages, **kw)
+        mark("plan")
+        shard.batch_csrs()
+        shard.norm("in", 0)
+        mark("csr_build")
+        shard.norm("out", 0)
+        mark("out_degree_exchange")
+        if timed["on"]:
+            plan_stats.append((src.numel(), shard.plan.n_remote, shard.plan.send_index.numel()))
+        return shard
+
+    timed = {"on": False}
 
     def step(t, record):
         src, dst = snapshots[t % n_snap]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
-        if record:
-            ev[0].record()
+        mark = Marks(record)
         if kind == "evolve_bf16":
             from spiral_amd.dtdg.types import Snapshot
 
@@ -397,49 +520,35 @@ def main():
             g.norm("in", 0)
             g.norm("out", 0)
             g.ndata["h"] = x_local
-            if record:
-                ev[1].record()
-                ev[2].record()
+            mark("csr_build")
             h, _ = model.encoder((Snapshot(g, t), ids))
-            if record:
-                ev[3].record()
-                ev[4].record()
-                stage_events.append(ev)
+            mark("encoder")
+            mark.done()
             return h
         if not multi:
             g = G.SnapshotGraph(src, dst, n_total)
             g.csr(wait=False)  # the first aggregation collects the build's status word
             g.norm("in", 0)
             g.norm("out", 0)
-            if record:
-                ev[1].record()
+            mark("csr_build")
             h = model.conv1(g, x_local)
-            if record:
-                ev[2].record()
+            mark("conv1")
             h = model.conv2(g, h)
         else:
-            shard = par.ShardedSnapshot(src, dst, part, stages=n_stages)
-            shard.batch_csrs()
-            shard.norm("in", 0)
-            shard.norm_global(0)
-            if record:
-                ev[1].record()
+            shard = sharded(src, dst, mark)
             h = par.sharded_graphconv(model.conv1, shard, x_local)
-            if record:
-                ev[2].record()
+            mark("conv1")
             h = par.sharded_graphconv(model.conv2, shard, h)
-        if record:
-            ev[3].record()
+        mark("conv2")
         out = model.rnn((h, ids))
-        if record:
-            ev[4].record()
-            stage_events.append(ev)
+        mark("recurrent")
+        mark.done()
         return out
 
     # ---- N>1 forward: one snapshot in two halves, the exchange in between ----------------
-    # front(t): CSR + norms, layer 1 on the replicated input (no exchange; aggregated
+    # front(t): plan + CSR + norms, layer 1 on the replicated input (no exchange; aggregated
     # into the local block first, projected afterwards), projection of
-    # layer 2, start of its all-gather.  back(t): layer-2 aggregation, recurrent update,
+    # layer 2, start of its all-to-all.  back(t): layer-2 aggregation, recurrent update,
     # MLP.  step t runs front(t) and then back(t-1): the rows of snapshot t travel while
     # snapshot t-1 is finished and snapshot t+1 is started.  Outputs equal the plain order
     # (encoders of different snapshots are independent, the recurrent order is kept).
@@ -448,40 +557,28 @@ def main():
     # exchange of snapshot t on the communicator's stream: they get a communicator of their own.
     deg_group = dist.new_group() if pipelined else None
 
-    def front(t, ev):
+    def front(t, mark):
         src, dst = snapshots[t % n_snap]
-        shard = par.ShardedSnapshot(src, dst, part, group=deg_group, stages=n_stages)
-        shard.global_view().csr()  # first, with edge positions: the same grouping then serves layer 2
-        shard.batch_csrs()
-        shard.norm("in", 0)
-        shard.norm_global(0)
-        if ev:
-            ev[1].record()
+        shard = sharded(src, dst, mark, group=deg_group)
         h = par.graphconv_replicated(model.conv1, shard, x_full)
-        if ev:
-            ev[2].record()
+        mark("conv1_replicated_input")
         in_flight.append((shard, par.graphconv_project(model.conv2, h, shard, payload)))
+        mark("conv2_project")
 
-    def back(ev):
+    def back(mark):
         shard, pending = in_flight.pop(0)
-        if ev:
-            ev[3].record()
         h = par.graphconv_aggregate(model.conv2, shard, pending)
-        if ev:
-            ev[4].record()
+        mark("conv2_wait_aggregate")
         out = model.rnn((h, ids))
-        if ev:
-            ev[5].record()
+        mark("recurrent")
         return out
 
     def pipelined_step(t, record):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if record else None
-        if ev:
-            ev[0].record()
-        front(t, ev)
-        out = back(ev) if len(in_flight) > 1 else None
-        if ev and out is not None:
-            stage_events.append(ev)
+        mark = Marks(record)
+        front(t, mark)
+        out = back(mark) if len(in_flight) > 1 else None
+        if out is not None:
+            mark.done()
         return out
 
     def barrier():
@@ -518,7 +615,7 @@ def main():
     def drain():
         with torch.no_grad():
             while in_flight:
-                back(None)
+                back(Marks(False))
 
     exchange_note = None
     for i in range(args.warmup):
@@ -542,6 +639,7 @@ def main():
     launch_log = []
     G.set_launch_log(launch_log)
     barrier()
+    timed["on"] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         # stage boundaries (five event records, each a packet of its own in the queue) on every
@@ -550,12 +648,39 @@ def main():
     drain()  # ... and ends with it empty: exactly `steps` whole snapshots inside
     barrier()
     elapsed = time.perf_counter() - t0
+    timed["on"] = False
     G.set_launch_log(None)
 
     if multi:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- what the exchange moved, per rank (N > 1) -----------------------------------------
+    exchange_stats = None
+    if multi:
+        k = max(len(plan_stats), 1)
+        mine = {"rank": rank, "rows_owned": n_local,
+                "edges": sum(p[0] for p in plan_stats) / k,
+                "rows_received": sum(p[1] for p in plan_stats) / k,
+                "rows_sent": sum(p[2] for p in plan_stats) / k}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        row_bytes = w["hidden"] * (2 if payload is not None else 4)
+        for r in per_rank:
+            r["bytes_received"] = r["rows_received"] * row_bytes
+            r["bytes_sent"] = r["rows_sent"] * row_bytes
+        mean_edges = sum(r["edges"] for r in per_rank) / world
+        exchange_stats = {
+            "per_rank": per_rank, "row_bytes": row_bytes,
+            "what": "averages per snapshot of the timed region; bytes are those of ONE row exchange "
+                    "(rows x hidden width x payload size)",
+            "row_exchanges_per_snapshot": (1 if pipelined else 2) + (1 if train else 0),
+            "nnz_imbalance": max(r["edges"] for r in per_rank) / max(mean_edges, 1.0),
+            "rows_received_imbalance": max(r["rows_received"] for r in per_rank)
+                                       / max(sum(r["rows_received"] for r in per_rank) / world, 1.0),
+            "all_gather_rows_per_rank": n_total - n_total // world,
+        }
 
     # ---- kernel-level numbers of the fused aggregation (this rank) ------------------------
     # every launch is priced with its own edge count, row count and width (layers of one model
@@ -570,13 +695,9 @@ def main():
     alg_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = sum(launch_bytes) / (sum(spmm_ms) * 1e-3) / 1e9
     stages = {}
-    if pipelined:
-        # front(t): [0,1) CSR, [1,2) layer 1, [2,3) projection + gather start;
-        # back(t-1): [3,4) wait + layer-2 aggregation, [4,5) recurrent
-        stage_names = ("csr_build", "conv1_replicated_input", "conv2_project", "conv2_wait_aggregate",
-                       "recurrent")
+    stage_names = [name for name, _ in stage_events[0][1:]] if stage_events else []
     for i, name in enumerate(stage_names):
-        stages[name + "_ms"] = sum(ev[i].elapsed_time(ev[i + 1]) for ev in stage_events) / max(len(stage_events), 1)
+        stages[name + "_ms"] = sum(ev[i][1].elapsed_time(ev[i + 1][1]) for ev in stage_events) / len(stage_events)
 
     if "csr_build_ms" in stages and stages["csr_build_ms"] > 0:
         # the build stage against its own roofline: counting-sort model E*(2i read + 2i write) + 2*N*p
@@ -636,8 +757,8 @@ def main():
             "reserved_bytes.all.peak", "allocated_bytes.all.peak")), file=sys.stderr, flush=True)
     if rank == 0 and args.per_step and stage_events:
         for i, ev in enumerate(stage_events):
-            series = [round(ev[j].elapsed_time(ev[j + 1]), 3) for j in range(len(stage_names))]
-            gap = round(stage_events[i - 1][len(stage_names)].elapsed_time(ev[0]), 3) if i else 0.0
+            series = [round(ev[j][1].elapsed_time(ev[j + 1][1]), 3) for j in range(len(stage_names))]
+            gap = round(stage_events[i - 1][-1][1].elapsed_time(ev[0][1]), 3) if i else 0.0
             print(f"step {i:3d} gap_before={gap:8.3f} " + " ".join(f"{n}={v:7.3f}" for n, v in zip(stage_names, series)),
                   file=sys.stderr, flush=True)
     if rank == 0:
@@ -675,8 +796,8 @@ def main():
                                             if not train and kind == "gcn_gru" and ops.USE_GRU_ROWS
                                             and ops.CELL_GEMM == "f16x3" and w["rnn_hidden"] == 128
                                             and w["hidden"] == 128 else "row-tile kernel / autograd path"),
-                       "exchange": exchange_note or (args.exchange if world > 1 and not train else
-                                                     ("plain" if world > 1 else None)),
+                       "exchange": exchange_note or (args.exchange if multi and not train else
+                                                     ("batched" if multi else None)),
                        "parallelism": (f"dst-row blocks x{world}, all-to-all of the source rows each rank's "
                                        f"edges name, {n_stages} batch(es) per exchange" +
                                        (", layer-1 input replicated, layer-2 exchange overlapped with the "
@@ -686,6 +807,7 @@ def main():
             "aggregation_edges_per_s": mean_nnz * world / (spmm_avg_ms * 1e-3),
             "train_ms_per_step": train_ms,
             "stages": stages,
+            "exchange_stats": exchange_stats,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if train else measured_traffic(args.workload, world, widths),

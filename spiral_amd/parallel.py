@@ -62,6 +62,11 @@ def edge_balanced_bounds(in_degree: torch.Tensor, world: int) -> List[int]:
     bounds = [0] + cuts + [n]
     for i in range(1, len(bounds)):
         bounds[i] = max(bounds[i], bounds[i - 1])
+    if n >= world:
+        # no empty block, even when one hub row holds more than its share of the edges (the
+        # device kernels take at least one row)
+        for i in range(1, world):
+            bounds[i] = min(max(bounds[i], bounds[i - 1] + 1), n - (world - i))
     return bounds
 
 
@@ -83,6 +88,38 @@ class RowPartition:
         b = torch.tensor(self.bounds[1:-1], dtype=torch.int64, device=ids.device)
         return torch.bucketize(ids, b, right=True)
 
+    def workspace(self, device: torch.device) -> "PlanWorkspace":
+        """The node-range scratch of this partition's exchange plans on `device`, made once."""
+        cache = self.__dict__.setdefault("_workspaces", {})
+        key = (device.type, device.index)
+        if key not in cache:
+            cache[key] = PlanWorkspace(self, device)
+        return cache[key]
+
+
+class PlanWorkspace:
+    """What an exchange plan needs over the whole node range, allocated once per partition and
+    device and reused by every snapshot (a plan leaves it as it found it):
+
+    mark    int32[N]  zero between plans; 1 at the remote ids a plan's edges name
+    csum    int32[N]  inclusive scan of mark (scratch)
+    colmap  int64[N]  table row of a node id: the own block's entries never change, a plan
+                      overwrites exactly the remote entries it reads afterwards
+
+    A plan is built on the current stream; plans of one partition must not be built on two
+    streams at once."""
+
+    def __init__(self, part: RowPartition, device: torch.device):
+        lo, hi = part.block()
+        self.mark = torch.zeros(part.n, dtype=torch.int32, device=device)
+        self.csum = torch.empty(part.n, dtype=torch.int32, device=device)
+        self.colmap = torch.full((part.n,), -1, dtype=torch.int64, device=device)
+        self.colmap[lo:hi] = torch.arange(hi - lo, dtype=torch.int64, device=device)
+        self.bounds_t = torch.tensor(part.bounds, dtype=torch.int64, device=device)
+        ends = self.bounds_t[1:]
+        self.end_idx = (ends - 1).clamp_(min=0)       # last node of every block ...
+        self.end_ok = (ends > 0).to(torch.int64)      # ... where there is one at or below it
+
 
 def _slice_bounds(count: int, stages: int) -> List[int]:
     """Cut `count` rows into `stages` consecutive slices; both ends of a transfer compute the
@@ -96,8 +133,14 @@ class ExchangePlan:
     Built from the global source ids of this rank's edges.  The source table this rank
     aggregates from is [own block (n_local rows, in place) | batch 0 | batch 1 | ...]; batch k
     holds slice k of the rows needed from every peer, peers in rank order, rows in ascending
-    id order.  `columns` gives every edge its row of that table.  Building the plan costs two
-    small all-to-alls (counts, then the requested row numbers) and two host round trips."""
+    id order.  `cols` gives every edge its row of that table.
+
+    Cost per snapshot: a mark and a scan over the node range in persistent buffers (no
+    allocation of that size), ONE host round trip (the P x P matrix of row counts, gathered on
+    the device and copied once: it holds what this rank needs from every peer and what every
+    peer needs from it), and one all-to-all of the requests.  A request carries the row number
+    inside its owner's block and this rank's count of edges that leave the row, so the owners
+    can add up out-degrees without any vector over the whole node range (`out_degree_table`)."""
 
     def __init__(self, src: torch.Tensor, part: RowPartition, group=None, stages: int = 1,
                  data_group=None):
@@ -112,16 +155,30 @@ class ExchangePlan:
         lo, hi = part.block()
         self.n_local = hi - lo
         src = src.to(torch.int64)
+        ws = part.workspace(dev)
 
-        # distinct sources by mark and scan over the node range (no sort)
-        flag = torch.zeros(part.n, dtype=torch.bool, device=dev)
-        flag[src] = True
-        flag[lo:hi] = False                                   # own rows stay where they are
-        uniq = torch.nonzero(flag).reshape(-1)                # ascending remote ids needed here
-        cut = torch.searchsorted(uniq, torch.tensor(part.bounds, dtype=torch.int64, device=dev)).tolist()
-        need = [cut[q + 1] - cut[q] for q in range(world)]    # rows needed from rank q (0 for self)
-        self.n_remote = len(uniq)
+        # distinct remote sources by mark and scan over the node range (no sort), their counts
+        # per owner read off the scan at the block ends
+        if world > 1:
+            ws.mark.index_fill_(0, src, 1)
+            ws.mark[lo:hi] = 0                                    # own rows stay where they are
+            torch.cumsum(ws.mark, 0, dtype=torch.int32, out=ws.csum)
+            upto = ws.csum.index_select(0, ws.end_idx).to(torch.int64) * ws.end_ok
+            need_dev = torch.diff(upto, prepend=upto.new_zeros(1))
+            matrix = torch.empty(world * world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(matrix, need_dev, group=group)
+            counts = matrix.view(world, world).cpu()              # the one host round trip
+            need = counts[rank].tolist()                          # rows needed from rank q (0 for self)
+            wanted = counts[:, rank].tolist()                     # rows rank p wants from this rank
+            self.n_remote = sum(need)
+            uniq = torch.nonzero_static(ws.mark, size=self.n_remote).reshape(-1)  # ascending ids
+            ws.mark.zero_()
+        else:
+            need, wanted, self.n_remote = [0], [0], 0
+            uniq = torch.empty(0, dtype=torch.int64, device=dev)
         self.n_table = self.n_local + self.n_remote
+        cut = [sum(need[:q]) for q in range(world + 1)]
+        self.need_per_peer, self.send_per_peer = need, wanted
 
         # table row of every needed id: batch-major, then owner, then ascending id
         peers = [q for q in range(world) if q != rank]
@@ -143,29 +200,25 @@ class ExchangePlan:
             table_row = pos - seg_pos_t[seg] + seg_row_t[seg]
         else:
             table_row = torch.empty(0, dtype=torch.int64, device=dev)
-        colmap = torch.full((part.n,), -1, dtype=torch.int64, device=dev)
-        colmap[lo:hi] = torch.arange(self.n_local, dtype=torch.int64, device=dev)
-        colmap[uniq] = table_row
-        self._colmap = colmap
+        self._uniq, self._table_row = uniq, table_row
+        ws.colmap[uniq] = table_row
+        self.cols = ws.colmap.index_select(0, src)            # table row of every edge's source
         # global id of every table row (own block first), e.g. to look up per-node vectors
         order = torch.empty(self.n_remote, dtype=torch.int64, device=dev)
         order[table_row - self.n_local] = uniq
         self.table_ids = torch.cat([torch.arange(lo, hi, dtype=torch.int64, device=dev), order])
+        self._partial_out = self._out_degree_table = None
 
-        # tell every owner which of its rows are wanted here
+        # tell every owner which of its rows are wanted here, and how many edges leave them here
         self.send_counts = [[0] * world for _ in range(self.stages)]
         self.send_index = torch.empty(0, dtype=torch.int64, device=dev)
-        self.send_per_peer: List[int] = [0] * world
+        self._asked = self._asked_count = self.send_index
         if world > 1:
-            counts_in = torch.tensor(need, dtype=torch.int64, device=dev)
-            counts_out = torch.empty_like(counts_in)
-            dist.all_to_all_single(counts_out, counts_in, group=group)
-            wanted = counts_out.tolist()                      # rows rank p wants from this rank
-            self.send_per_peer = wanted
-            bounds_t = torch.tensor(part.bounds, dtype=torch.int64, device=dev)
-            request = uniq - bounds_t[part.owner(uniq)]       # row inside the owner's block
-            asked = torch.empty(sum(wanted), dtype=torch.int64, device=dev)
-            dist.all_to_all_single(asked, request, wanted, need, group=group)
+            request = uniq - ws.bounds_t[part.owner(uniq)]    # row inside the owner's block
+            message = torch.stack([request, self._partial().index_select(0, table_row)], 1)
+            asked = torch.empty(sum(wanted), 2, dtype=torch.int64, device=dev)
+            dist.all_to_all_single(asked, message, wanted, need, group=group)
+            self._asked, self._asked_count = asked[:, 0].contiguous(), asked[:, 1].contiguous()
             # reorder the requests batch-major, the order the rows are sent in
             starts = [sum(wanted[:p]) for p in range(world)]
             pieces = []
@@ -173,18 +226,73 @@ class ExchangePlan:
                 for p in range(world):
                     c = _slice_bounds(wanted[p], self.stages)
                     self.send_counts[k][p] = c[k + 1] - c[k]
-                    pieces.append(asked[starts[p] + c[k]: starts[p] + c[k + 1]])
-            self.send_index = torch.cat(pieces) if pieces else asked
+                    pieces.append(self._asked[starts[p] + c[k]: starts[p] + c[k + 1]])
+            self.send_index = torch.cat(pieces) if self.stages > 1 else self._asked
         self.send_batch_start = [sum(sum(c) for c in self.send_counts[:k]) for k in range(self.stages + 1)]
+        self._return_csrs = None
 
     def columns(self, src: torch.Tensor) -> torch.Tensor:
-        """Row of this rank's source table for every global source id of its edges."""
-        return self._colmap[src.to(torch.int64)]
+        """Row of this rank's source table for global source ids (own ids or ids the plan's
+        edges name).  The plan's own edges have theirs in `cols`; this is the lookup for other
+        id lists, by binary search in the plan's sorted remote ids."""
+        src = src.to(torch.int64)
+        lo, hi = self.part.block()
+        own = (src >= lo) & (src < hi)
+        if self.n_remote == 0:
+            return src - lo
+        pos = torch.searchsorted(self._uniq, src).clamp_(max=self.n_remote - 1)
+        return torch.where(own, src - lo, self._table_row[pos])
 
     def batch_of_column(self, cols: torch.Tensor) -> torch.Tensor:
         """Batch whose arrival completes a column: own rows and batch 0 are 0."""
         b = torch.tensor(self.batch_start[1:-1], dtype=torch.int64, device=cols.device)
         return torch.bucketize(cols, b, right=True)
+
+    def _partial(self) -> torch.Tensor:
+        """Edges of this rank that leave every table row (int64 [n_table]).  The ids were
+        range-checked by the gather through colmap, so the count waits for no status word."""
+        if self._partial_out is None:
+            self._partial_out = kernels.degree(self.cols, self.n_table, validated=True).to(torch.int64)
+        return self._partial_out
+
+    def out_degree_table(self) -> torch.Tensor:
+        """Out-degree in the whole graph (int64) of every row of this rank's source table.
+        A rank counts the edges that leave a row among its own edges; the counts of remote rows
+        travelled to the rows' owners with the requests; the owners add what they were sent to
+        their own counts and answer every request with the total: one more all-to-all of
+        n_remote numbers, against an all-reduce over the whole node range."""
+        if self._out_degree_table is None:
+            partial = self._partial()
+            if self.part.world == 1:
+                self._out_degree_table = partial
+            else:
+                own = partial[: self.n_local].clone()
+                own.index_add_(0, self._asked, self._asked_count)   # integer adds: order-free
+                reply = own.index_select(0, self._asked)
+                back = torch.empty(self.n_remote, dtype=torch.int64, device=own.device)
+                dist.all_to_all_single(back, reply, self.need_per_peer, self.send_per_peer, group=self.group)
+                table = torch.empty(self.n_table, dtype=torch.int64, device=own.device)
+                table[: self.n_local] = own
+                table[self._table_row] = back
+                self._out_degree_table = table
+        return self._out_degree_table
+
+    def return_csrs(self) -> list:
+        """For the backward pass: per batch, the rows that come back from the peers grouped by
+        the own row they add to (a CSR with one column per returned row, columns numbered over
+        all batches), so that the owner's additions are one aggregation launch per batch with a
+        fixed order of summation inside a row (peers in rank order) and no atomics."""
+        if self._return_csrs is None:
+            self._return_csrs = []
+            total = self.send_index.numel()
+            for k in range(self.stages):
+                a, b = self.send_batch_start[k], self.send_batch_start[k + 1]
+                if a == b:
+                    self._return_csrs.append(None)
+                    continue
+                pos = torch.arange(a, b, dtype=torch.int64, device=self.send_index.device)
+                self._return_csrs.append(kernels.build_csr(self.send_index[a:b], pos, self.n_local, total))
+        return self._return_csrs
 
 
 class PendingTable:
@@ -239,29 +347,46 @@ def exchange_rows_async(z_local: torch.Tensor, plan: ExchangePlan,
     return PendingTable(table, works, send, prescaled)
 
 
+def _return_rows_async(g_remote: torch.Tensor, plan: ExchangePlan):
+    """Start the reverse transfer of the backward pass: `g_remote` [n_remote, F] is the gradient
+    of the remote part of this rank's source table (batch-major, as the rows arrived); every
+    batch goes back to the owners of its rows with one all-to-all, queued back to back.
+    Returns (buffer that receives the rows coming back to this rank, one handle per batch)."""
+    f = g_remote.shape[1]
+    back = g_remote.new_empty(plan.send_index.numel(), f)
+    works = []
+    for k in range(plan.stages):
+        inp = g_remote[plan.batch_start[k] - plan.n_local: plan.batch_start[k + 1] - plan.n_local]
+        out = back[plan.send_batch_start[k]: plan.send_batch_start[k + 1]]
+        works.append(dist.all_to_all_single(out, inp, plan.send_counts[k], plan.recv_counts[k],
+                                            group=plan.data_group, async_op=True))
+    return back, works
+
+
+def _add_returned_rows(g_local: torch.Tensor, back: torch.Tensor, works: list, plan: ExchangePlan) -> torch.Tensor:
+    """Add the rows that came back to the own block's gradient, batch by batch as they land:
+    one aggregation launch per batch over the plan's return CSR (row = own row, columns = the
+    returned rows that belong to it, peers in rank order), which adds into `g_local` in place.
+    No atomics, a fixed order inside every row: bit-reproducible."""
+    csrs = plan.return_csrs()
+    for k, work in enumerate(works):
+        if work is not None:
+            work.wait()
+        if csrs[k] is not None:
+            kernels.aggregate(csrs[k], back, None, None, None, None, None, 0.01, out=g_local,
+                              accumulate=True, finalize=False)
+    return g_local
+
+
 def _return_rows(g_table: torch.Tensor, plan: ExchangePlan) -> torch.Tensor:
-    """The reverse transfer for the backward pass: the remote part of a gradient over the
-    source table goes back to the owners of those rows, who add what they receive to their
-    own block's part.  Returns the gradient of this rank's block [n_local, F].  The rows one
-    peer sends back are distinct, so the additions are done peer by peer without atomics
-    (bit-reproducible)."""
+    """The reverse transfer for a gradient over the whole source table [n_table, F]: the remote
+    part goes back to the owners, who add what they receive to their own block's part.
+    Returns the gradient of this rank's block [n_local, F]."""
     g_local = g_table[: plan.n_local].clone()
     if plan.part.world == 1:
         return g_local
-    f = g_table.shape[1]
-    back = g_table.new_empty(plan.send_index.numel(), f)
-    for k in range(plan.stages):
-        inp = g_table[plan.batch_start[k]: plan.batch_start[k + 1]].contiguous()
-        out = back[plan.send_batch_start[k]: plan.send_batch_start[k + 1]]
-        dist.all_to_all_single(out, inp, plan.send_counts[k], plan.recv_counts[k], group=plan.data_group)
-    off = 0
-    for k in range(plan.stages):
-        for p in range(plan.part.world):
-            c = plan.send_counts[k][p]
-            if c:
-                g_local.index_add_(0, plan.send_index[off: off + c], back[off: off + c])
-            off += c
-    return g_local
+    back, works = _return_rows_async(g_table[plan.n_local:], plan)
+    return _add_returned_rows(g_local, back, works, plan)
 
 
 def _with_indices(csr, indices: torch.Tensor, n_cols: int):
@@ -285,11 +410,12 @@ class ShardedSnapshot(G.NormalisedAdjacency):
         self.n_local = hi - lo
         self.src_global = src.to(torch.int64)
         self.plan = ExchangePlan(self.src_global, part, group, stages, data_group)
-        self.cols = self.plan.columns(self.src_global)
+        self.cols = self.plan.cols
         self.dst_rows = dst.to(torch.int64) - lo
         self._csr = self._csr_t = self._batch_csrs = self._global = None
-        self._out_degree = None
+        self._csr_t_parts = None
         self._norms = {}
+        self._batch_scales = {}
 
     @classmethod
     def from_global(cls, src, dst, part: RowPartition, group=None, stages: int = 1,
@@ -310,6 +436,20 @@ class ShardedSnapshot(G.NormalisedAdjacency):
             self._csr_t = kernels.build_csr(self.cols, self.dst_rows, self.plan.n_table, self.n_local)
         return self._csr_t
 
+    def csr_t_parts(self):
+        """The by-source grouping in two pieces, for a backward pass that sends the remote rows'
+        gradient on its way before it computes its own: (edges whose source row is remote,
+        grouped by table row - n_local; edges whose source is an own row, grouped by it)."""
+        if self._csr_t_parts is None:
+            remote = self.cols >= self.n_local
+            own = ~remote
+            self._csr_t_parts = (
+                None if self.plan.n_remote == 0 else
+                kernels.build_csr(self.cols[remote] - self.n_local, self.dst_rows[remote],
+                                  self.plan.n_remote, self.n_local),
+                kernels.build_csr(self.cols[own], self.dst_rows[own], self.n_local, self.n_local))
+        return self._csr_t_parts
+
     def batch_csrs(self) -> list:
         """One CSR per batch of the plan: the edges whose source row arrives with that batch
         (own rows count to batch 0)."""
@@ -325,15 +465,20 @@ class ShardedSnapshot(G.NormalisedAdjacency):
                                                               self.n_local, self.plan.n_table))
         return self._batch_csrs
 
-    def out_degree(self) -> torch.Tensor:
-        """Out-degree of every node of the graph (int32 [N]): per-rank partial counts summed
-        with one all-reduce per snapshot."""
-        if self._out_degree is None:
-            deg = kernels.degree(self.src_global, self.part.n).to(torch.int32)
-            if self.part.world > 1:
-                dist.all_reduce(deg, group=self.group)
-            self._out_degree = deg
-        return self._out_degree
+    def batch_edge_scale(self, k: int, norm: str) -> Optional[torch.Tensor]:
+        """Per-nonzero source normaliser of batch k's CSR (cached per snapshot and norm)."""
+        if norm not in ("left", "both"):
+            return None
+        key = (k, norm)
+        if key not in self._batch_scales:
+            csr = self.batch_csrs()[k]
+            self._batch_scales[key] = self.norm("out", 0 if norm == "both" else 1).index_select(
+                0, csr.indices.to(torch.int64))
+        return self._batch_scales[key]
+
+    def out_degree_table(self) -> torch.Tensor:
+        """Out-degree in the whole graph of every row of this rank's source table (int64)."""
+        return self.plan.out_degree_table()
 
     def _norm_of(self, deg: torch.Tensor, mode: int) -> torch.Tensor:
         d = deg.to(torch.float32).clamp_(min=1)
@@ -347,21 +492,25 @@ class ShardedSnapshot(G.NormalisedAdjacency):
             if side == "in":
                 self._norms[key] = self._norm_of(self.csr().degrees(), mode)
             else:
-                self._norms[key] = self.norm_global(mode).index_select(0, self.plan.table_ids)
+                self._norms[key] = self._norm_of(self.out_degree_table(), mode)
         return self._norms[key]
 
     def norm_global(self, mode: int) -> torch.Tensor:
-        """Source normaliser of every node of the graph [N]."""
+        """Source normaliser as a vector over the whole node range [N]: the nodes this rank's
+        edges name (and its own) hold their value, every other entry is 1 and is never read by
+        this rank's aggregations.  Allocates over the node range; the layers use the table
+        form (`norm('out', mode)`)."""
         key = ("global", mode)
         if key not in self._norms:
-            self._norms[key] = self._norm_of(self.out_degree(), mode)
+            full = torch.ones(self.part.n, dtype=torch.float32, device=self.cols.device)
+            full[self.plan.table_ids] = self.norm("out", mode)
+            self._norms[key] = full
         return self._norms[key]
 
     def norm_out_local(self, mode: int) -> torch.Tensor:
         """Source normaliser of this rank's own rows [n_local]: what the owner multiplies its
         projected rows by before they travel."""
-        lo, hi = self.part.block()
-        return self.norm_global(mode)[lo:hi]
+        return self.norm("out", mode)[: self.n_local]
 
     def global_view(self) -> "_GlobalSources":
         """The same block with sources numbered by global node id, for inputs every rank holds
@@ -380,8 +529,8 @@ class _GlobalSources(G.NormalisedAdjacency):
 
     def csr(self, want_eid: bool = False, wait: bool = True):
         if self._csr is None:
-            base = self.shard.csr(want_eid=True)
-            cols = self.shard.src_global.index_select(0, base.eid.to(torch.int64)).to(base.indices.dtype)
+            base = self.shard.csr()
+            cols = self.shard.plan.table_ids.index_select(0, base.indices.to(torch.int64)).to(base.indices.dtype)
             self._csr = _with_indices(base, cols, self.shard.part.n)
         return self._csr
 
@@ -394,15 +543,56 @@ class _GlobalSources(G.NormalisedAdjacency):
     def norm(self, side: str, mode: int) -> torch.Tensor:
         return self.shard.norm("in", mode) if side == "in" else self.shard.norm_global(mode)
 
+    def edge_scale(self, direction: str, norm: str, edge_weight: Optional[torch.Tensor] = None):
+        """Forward weights from the table form of the source normaliser (the block's CSR with
+        table column numbers has the same order of nonzeros), so that nothing over the whole
+        node range is built for a layer that only runs forward."""
+        if direction == "fwd" and edge_weight is None and norm in ("left", "both"):
+            cache = self._edge_scale_cache()
+            key = (direction, norm)
+            if key not in cache:
+                base = self.shard.csr()
+                cache[key] = self.shard.norm("out", 0 if norm == "both" else 1).index_select(
+                    0, base.indices.to(torch.int64))
+            return cache[key]
+        return super().edge_scale(direction, norm, edge_weight)
+
+
+def _aggregate_batches(shard: ShardedSnapshot, pending: PendingTable, norm: str, dst_scale, bias, act,
+                       slope) -> torch.Tensor:
+    """The aggregation of a source table into this rank's destination block, batch by batch as
+    the batches land (the sum over the sources of batch k is added while batch k+1 is on the
+    wire); the last launch applies destination scale, bias and activation."""
+    csrs = shard.batch_csrs()
+    rst = None
+    for k, csr in enumerate(csrs):
+        table = pending.wait(k)
+        edge_w = None if pending.prescaled else shard.batch_edge_scale(k, norm)
+        if len(csrs) == 1:
+            rst = kernels.aggregate(csr, table, None, edge_w, dst_scale, bias, act, slope,
+                                    out_dtype=torch.float32)
+        else:
+            rst = kernels.aggregate(csr, table, None, edge_w, dst_scale, bias, act, slope, out=rst,
+                                    out_dtype=torch.float32, accumulate=k > 0, finalize=k == len(csrs) - 1)
+    return rst
+
 
 class _ShardedAggregate(torch.autograd.Function):
+    """The exchange + aggregation of one layer under autograd.
+
+    forward   the batches of the plan are queued back to back and aggregated as they arrive
+              (`_aggregate_batches`, the chain the inference path uses);
+    backward  the gradient of the REMOTE rows of the source table is computed first and sent on
+              its way (asynchronous all-to-alls, one per batch); the gradient of the own rows is
+              computed while it travels; the rows that come back are added batch by batch with
+              one launch each (`_add_returned_rows`)."""
+
     @staticmethod
     def forward(ctx, x_local, bias, shard: ShardedSnapshot, norm, act, slope):
         mode = 0 if norm == "both" else 1
-        table = exchange_rows_async(x_local, shard.plan).wait()
         dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
-        y = kernels.aggregate(shard.csr(), table, None, shard.edge_scale("fwd", norm), dst_scale,
-                              None if bias is None else bias.detach(), act, slope)
+        y = _aggregate_batches(shard, exchange_rows_async(x_local, shard.plan), norm, dst_scale,
+                               None if bias is None else bias.detach(), act, slope)
         ctx.shard, ctx.norm, ctx.act, ctx.slope, ctx.has_bias = shard, norm, act, slope, bias is not None
         ctx.save_for_backward(y if act not in (None, "none") else None)
         return y
@@ -419,10 +609,31 @@ class _ShardedAggregate(torch.autograd.Function):
         g_x = None
         if ctx.needs_input_grad[0]:
             mode = 0 if norm == "both" else 1
+            plan, n_local = shard.plan, shard.n_local
+            g_p = g_p.contiguous()
             out_scale = shard.norm("out", mode) if norm in ("left", "both") else None
-            g_table = kernels.aggregate(shard.csr_t(), g_p.contiguous(), None,
-                                        shard.edge_scale("bwd", norm), out_scale, None, None)
-            g_x = _return_rows(g_table, shard.plan)
+            in_w = shard.norm("in", mode) if norm in ("right", "both") else None
+            if plan.part.world == 1:
+                edge_w = shard.edge_scale("bwd", norm)
+                g_table = kernels.aggregate(shard.csr_t(), g_p, None, edge_w, out_scale, None, None)
+                g_x = _return_rows(g_table, plan)
+            else:
+                remote_t, own_t = shard.csr_t_parts()
+
+                def weights(csr):
+                    return None if in_w is None else in_w.index_select(0, csr.indices.to(torch.int64))
+
+                if remote_t is None:  # no edge of this block leaves a remote row: nothing to send,
+                    g_remote = g_p.new_empty(0, g_p.shape[1])  # but the collectives are everyone's
+                else:
+                    g_remote = kernels.aggregate(remote_t, g_p, None, weights(remote_t),
+                                                 None if out_scale is None else out_scale[n_local:].contiguous(),
+                                                 None, None)
+                back, works = _return_rows_async(g_remote, plan)
+                g_own = kernels.aggregate(own_t, g_p, None, weights(own_t),
+                                          None if out_scale is None else out_scale[:n_local].contiguous(),
+                                          None, None)
+                g_x = _add_returned_rows(g_own, back, works, plan)
         return g_x, g_b, None, None, None, None
 
 
@@ -538,12 +749,6 @@ def graphconv_project(conv, feat_local: torch.Tensor, shard: ShardedSnapshot,
     return exchange_rows_async(feat_local @ w, plan, payload_dtype)
 
 
-def _edge_scale_of(shard, csr, norm: str) -> Optional[torch.Tensor]:
-    if norm not in ("left", "both"):
-        return None
-    return shard.norm("out", 0 if norm == "both" else 1).index_select(0, csr.indices.to(torch.int64))
-
-
 def graphconv_aggregate(conv, shard: ShardedSnapshot, pending: PendingTable) -> torch.Tensor:
     """Second half without autograd: the aggregation of the source table into this rank's
     destination block, batch by batch as the batches arrive, then bias/activation (and W when
@@ -554,19 +759,7 @@ def graphconv_aggregate(conv, shard: ShardedSnapshot, pending: PendingTable) -> 
     mode = 0 if norm == "both" else 1
     dst_scale = shard.norm("in", mode) if norm in ("right", "both") else None
     bias = conv.bias.detach() if (first and conv.bias is not None) else None
-    act = code if first else None
-    csrs = shard.batch_csrs()
-    rst = None
-    for k, csr in enumerate(csrs):
-        table = pending.wait(k)
-        edge_w = None if pending.prescaled else _edge_scale_of(shard, csr, norm)
-        last = k == len(csrs) - 1
-        if len(csrs) == 1:
-            rst = kernels.aggregate(csr, table, None, edge_w, dst_scale, bias, act, slope,
-                                    out_dtype=torch.float32)
-        else:
-            rst = kernels.aggregate(csr, table, None, edge_w, dst_scale, bias, act, slope, out=rst,
-                                    out_dtype=torch.float32, accumulate=k > 0, finalize=last)
+    rst = _aggregate_batches(shard, pending, norm, dst_scale, bias, code if first else None, slope)
     if first:
         return rst if unfused is None else unfused(rst)
     return _finish(conv, rst, code, slope, unfused)

@@ -33,7 +33,7 @@ def _stage_through_host():
             return Done() if was_async else r
         return call
 
-    for name in ("all_to_all_single", "all_reduce"):
+    for name in ("all_to_all_single", "all_gather_into_tensor", "all_reduce"):
         setattr(dist, name, staged(getattr(dist, name)))
 
 

@@ -48,9 +48,12 @@ def _cpu_kernels():
             if bias is not None:
                 raw = raw + bias
             raw = torch.from_numpy(orc._activation(raw.numpy(), act, slope))
+        if out is not None:  # the library writes into the tensor it is given
+            out.copy_(raw)
+            return out
         return raw
 
-    def degree(ids, n):
+    def degree(ids, n, validated=False):
         return torch.from_numpy(orc.degree(ids.numpy(), n))
 
     def act_bias_bwd(g_y, y, act, slope, want_gb):
@@ -183,3 +186,114 @@ def test_single_rank_plan_needs_no_process_group():
     assert plan.columns(torch.tensor([5, 0, 3])).tolist() == [5, 0, 3]
     pending = par.exchange_rows_async(torch.arange(12.0).reshape(6, 2), plan)
     assert torch.equal(pending.wait(), torch.arange(12.0).reshape(6, 2))
+
+
+# ---- shapes a first run on real hardware must not trip over ---------------------------------
+def _skewed_problem(bounds):
+    """A graph laid out against fixed block bounds so that the exchange has every awkward
+    shape at once: block 0 names no remote row at all; block 1 needs many rows of block 0 and a
+    single row of the last block (uneven per-peer counts, fewer rows than batches); the last
+    block needs rows of block 1 only (a per-peer count of zero in both directions with block
+    0).  Blocks in between, if any, are empty or have no edges."""
+    rng = np.random.default_rng(17)
+    n = bounds[-1]
+    first, second, last = (0, bounds[1]), None, None
+    blocks = [(bounds[q], bounds[q + 1]) for q in range(len(bounds) - 1) if bounds[q + 1] > bounds[q]]
+    first, second, last = blocks[0], blocks[1], blocks[-1]
+    src, dst = [], []
+
+    def edges(s_range, d_range, count):
+        src.append(rng.integers(*s_range, count))
+        dst.append(rng.integers(*d_range, count))
+
+    edges(first, first, 200)                       # block 0: own sources only
+    edges(first, second, 300)                      # block 1: many rows of block 0 ...
+    src.append(np.full(5, last[0] + 3))            # ... one row of the last block (5 edges)
+    dst.append(rng.integers(*second, 5))
+    edges(second, second, 50)
+    edges(second, last, 120)                       # last block: rows of block 1 and its own
+    edges(last, last, 40)
+    src, dst = np.concatenate(src).astype(np.int64), np.concatenate(dst).astype(np.int64)
+    fi, fo = 6, 6
+    x = rng.standard_normal((n, fi)).astype(np.float32)
+    w = (rng.standard_normal((fi, fo)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(fo).astype(np.float32)
+    return n, src, dst, x, w, b
+
+
+def _skew_worker(rank, world, port, bounds, stages, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from spiral_amd.core.types import GraphConv
+
+        par.kernels = _cpu_kernels()
+        n, src, dst, x, w, b = _skewed_problem(bounds)
+        part = par.RowPartition(n, bounds, rank, world)
+        lo, hi = part.block()
+        conv = GraphConv(x.shape[1], w.shape[1], activation=F.relu, allow_zero_in_degree=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w))
+            conv.bias.copy_(torch.from_numpy(b))
+        out = dict(y=[], gx=[], gw=[], gb=[], need=[], wanted=[], deg=[])
+        for _ in range(2):   # twice on one partition: the second plan finds the workspace clean
+            shard = par.ShardedSnapshot.from_global(torch.from_numpy(src), torch.from_numpy(dst), part,
+                                                    stages=stages)
+            conv.zero_grad()
+            xl = torch.tensor(x[lo:hi], requires_grad=True)
+            y = par.sharded_graphconv(conv, shard, xl)
+            (y ** 2).sum().backward()
+            par.allreduce_gradients(conv)
+            out["y"].append(y.detach().numpy())
+            out["gx"].append(xl.grad.numpy())
+            out["gw"].append(conv.weight.grad.numpy().copy())
+            out["gb"].append(conv.bias.grad.numpy().copy())
+            out["need"].append(list(shard.plan.need_per_peer))
+            out["wanted"].append(list(shard.plan.send_per_peer))
+            out["deg"].append((shard.plan.table_ids.numpy(), shard.out_degree_table().numpy()))
+        ws = part.workspace(torch.device("cpu"))
+        out["mark_clean"] = int(ws.mark.abs().sum()) == 0
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bounds,stages", [([0, 30, 60, 90], 1), ([0, 30, 60, 90], 3),
+                                           ([0, 30, 30, 60, 90], 2)])
+def test_exchange_with_zero_counts_uneven_counts_and_an_empty_block(bounds, stages):
+    world = len(bounds) - 1
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_skew_worker, args=(world, _free_port(), bounds, stages, results), nprocs=world, join=True)
+        results = dict(results)
+    n, src, dst, x, w, b = _skewed_problem(bounds)
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    y_ref = orc.graphconv_torch(src, dst, n, xt, wt, bt, act="relu")
+    (y_ref ** 2).sum().backward()
+    out_deg = np.bincount(src, minlength=n)
+
+    def rel(a, ref):
+        return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+    last = world - 1
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        res = results[r]
+        assert res["mark_clean"]
+        for rep in range(2):
+            if hi > lo:
+                assert rel(res["y"][rep], y_ref.detach().numpy()[lo:hi]) < 1e-5
+                assert rel(res["gx"][rep], xt.grad.numpy()[lo:hi]) < 1e-5
+            assert rel(res["gw"][rep], wt.grad.numpy()) < 1e-5
+            assert rel(res["gb"][rep], bt.grad.numpy()) < 1e-5
+            ids, deg = res["deg"][rep]
+            np.testing.assert_array_equal(deg, out_deg[ids])     # whole-graph out-degrees, table order
+        assert res["need"][0] == res["need"][1] and res["wanted"][0] == res["wanted"][1]
+    second = 1 if world == 3 else 2
+    assert sum(results[0]["need"][0]) == 0                          # block 0 needs nothing
+    assert results[second]["need"][0][last] == 1                    # one row of the last block
+    assert results[second]["need"][0][0] > 20                       # many of block 0
+    assert results[last]["need"][0][0] == 0 and results[0]["wanted"][0][last] == 0
+    if world == 4:                                                  # the empty block: no rows either way
+        assert sum(results[1]["need"][0]) == 0 and sum(results[1]["wanted"][0]) == 0
