@@ -90,22 +90,27 @@ def self_launch(argv) -> int:
     reader = threading.Thread(target=pump, daemon=True)
     reader.start()
     grace = float(os.environ.get("SPMI_BENCH_LAUNCH_GRACE_S", "20"))
-    status, failed_at = 0, None
-    while any(p.poll() is None for p in procs):
+    status, failed_at, reported = 0, None, set()
+
+    def check():
+        nonlocal status, failed_at
         for r, p in enumerate(procs):
             code = p.poll()
-            if code not in (None, 0) and status == 0:
-                status, failed_at = code, time.monotonic()
+            if code not in (None, 0) and r not in reported:
+                reported.add(r)
                 print(f"bench.py launcher: rank {r} exited with status {code}", file=sys.stderr, flush=True)
+                if status == 0:
+                    status, failed_at = code, time.monotonic()
+
+    while any(p.poll() is None for p in procs):
+        check()
         if failed_at is not None and time.monotonic() - failed_at > grace:
             for p in procs:  # exactly the processes started above
                 if p.poll() is None:
                     p.kill()
         time.sleep(0.05)
+    check()
     reader.join(timeout=10)
-    for p in procs:
-        if p.returncode != 0 and status == 0:
-            status = p.returncode
     return status if status >= 0 else 128 - status
 
 
@@ -414,6 +419,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
+        if world == 1 and "MASTER_PORT" not in os.environ:  # one rank, no launcher: a rendezvous of its own
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                                  MASTER_PORT=str(sock.getsockname()[1]))
         if rehearse:
             dist.init_process_group("gloo")
             _stage_collectives_through_host()
@@ -644,7 +656,8 @@ def main():
     for i in range(args.steps):
         # stage boundaries (five event records, each a packet of its own in the queue) on every
         # fourth step; the aggregation launches are timed on all of them
-        run(args.warmup + i, args.per_step or i % 4 == 0)
+        # (the pipelined step finishes a snapshot from its second step on)
+        run(args.warmup + i, args.per_step or i % 4 == (1 if pipelined else 0))
     drain()  # ... and ends with it empty: exactly `steps` whole snapshots inside
     barrier()
     elapsed = time.perf_counter() - t0

@@ -564,6 +564,150 @@ def edge_head_forward(kind, embs, pairs, mem_h, params, mlp_layers, mem_c=None, 
     return (y, mem_h, mem_c) if kind == "lstm" else (y, mem_h)
 
 
+def mrr_numpy(pred_pos: np.ndarray, pred_neg: np.ndarray) -> float:
+    """Mean reciprocal rank as ogb 1.3.3's `_eval_mrr` publishes it (the evaluator the reference
+    calls at examples/tf/link_prediction_sliding_window.py:142-146): every positive against its
+    own row of negatives, rank = 1 + mean of the optimistic and the pessimistic count of
+    negatives scored above it.  ogb is not installable here: parity unpinned."""
+    pos = np.asarray(pred_pos, dtype=np.float64).reshape(-1, 1)
+    neg = np.asarray(pred_neg, dtype=np.float64)
+    rank = 0.5 * ((neg > pos).sum(1) + (neg >= pos).sum(1)) + 1.0
+    return float((1.0 / rank).mean())
+
+
+def link_prediction_loop_torch(edges, nodes, n_timestamps, tasks, train_ts, eval_t, convs, kind, rnn_params,
+                               mlp_layers, mem_h0, mem_c0=None, lr=1e-3, epochs=1, loss_order="bce",
+                               eval_negatives_per_node=1000, positives_per_node=2, bn_momentum=0.1,
+                               bn_eps=1e-5):
+    """The link-prediction training loop of examples/tf/link_prediction_sliding_window.py:99-146
+    on the torch path, restated with plain torch-CPU tensor ops (differentiable, float32):
+
+      per epoch: node memory back to its initial value (:101, injected instead of re-drawn);
+      for t in train_ts (:104): snapshot t (prefix of the edge table, types.py:183-198) minus the
+      positive edges of its task (:105-106), GraphConv stack (leaky_relu), recurrent step on the
+      distinct nodes of the target pairs with the detached state written back
+      (tf/sequentialDecoder/baseModel.py:32-46,154-164), pair-wise concatenation + MLP with
+      train-mode BatchNorm + sigmoid (tf/simpleDecoder.py:90-97), loss, Adam(lr, eps 1e-8) (:98);
+      afterwards the held-out snapshot `eval_t` in inference mode (BatchNorm running statistics,
+      memory not written) and the MRR of its positives against `eval_negatives_per_node`
+      negatives per evaluated node (:128-146).
+
+    loss_order: "bce" = binary cross-entropy of the prediction against the label (what the
+    script means); "swapped" = the script as written (:109 passes (prediction, label) to a
+    Keras loss whose signature is (y_true, y_pred)): -mean(p log l' + (1-p) log(1-l')) with the
+    label clipped to [1e-7, 1-1e-7], which is linear in the prediction.
+
+    tasks[t] = (pairs int64 [m, 2], labels float [m], ids of the positive edges in the table).
+    convs = [(W [in,out], b)], rnn_params[k] = (w_ih, w_hh, b_ih, b_hh), mlp_layers = list of
+    {'w','b'} / {'gamma','beta','mean','var'} dicts in module order (a ReLU follows every
+    BatchNorm, a sigmoid the last Linear); all numpy, copied.  Returns a dict with the loss of
+    every step, the gradients of the first step, the final parameters, the evaluation
+    predictions and the MRR."""
+    import torch
+
+    def leaf(a):
+        return torch.tensor(np.asarray(a, dtype=np.float32), requires_grad=True)
+
+    convs_t = [(leaf(w), leaf(b)) for w, b in convs]
+    rnn_t = [tuple(leaf(a) for a in layer) for layer in rnn_params]
+    mlp_t = []
+    for ly in mlp_layers:
+        if "w" in ly:
+            mlp_t.append({"w": leaf(ly["w"]), "b": leaf(ly["b"])})
+        else:
+            mlp_t.append({"gamma": leaf(ly["gamma"]), "beta": leaf(ly["beta"]),
+                          "mean": torch.tensor(np.asarray(ly["mean"], dtype=np.float32)),
+                          "var": torch.tensor(np.asarray(ly["var"], dtype=np.float32))})
+    params = [t for pair in convs_t for t in pair] + [t for layer in rnn_t for t in layer] + \
+             [ly[k] for ly in mlp_t for k in ("w", "b", "gamma", "beta") if k in ly]
+    opt = torch.optim.Adam(params, lr=lr, eps=1e-8)
+
+    def cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+        hd = h.shape[1]
+        gi, gh = x @ w_ih.T + b_ih, h @ w_hh.T + b_hh
+        if kind == "gru":
+            r = torch.sigmoid(gi[:, :hd] + gh[:, :hd])
+            z = torch.sigmoid(gi[:, hd:2 * hd] + gh[:, hd:2 * hd])
+            n = torch.tanh(gi[:, 2 * hd:] + r * gh[:, 2 * hd:])
+            return (1 - z) * n + z * h, None
+        if kind == "rnn":
+            return torch.tanh(gi + gh), None
+        g = gi + gh
+        i, f = torch.sigmoid(g[:, :hd]), torch.sigmoid(g[:, hd:2 * hd])
+        c2 = f * c + i * torch.tanh(g[:, 2 * hd:3 * hd])
+        return torch.sigmoid(g[:, 3 * hd:]) * torch.tanh(c2), c2
+
+    def head(z, training):
+        h = z
+        for ly in mlp_t:
+            if "w" in ly:
+                h = h @ ly["w"].T + ly["b"]
+            else:
+                if training:
+                    mean, var = h.mean(0), h.var(0, unbiased=False)
+                    with torch.no_grad():
+                        ly["mean"] = (1 - bn_momentum) * ly["mean"] + bn_momentum * mean
+                        ly["var"] = (1 - bn_momentum) * ly["var"] + bn_momentum * h.var(0, unbiased=True)
+                else:
+                    mean, var = ly["mean"], ly["var"]
+                h = torch.relu((h - mean) / torch.sqrt(var + bn_eps) * ly["gamma"] + ly["beta"])
+        return torch.sigmoid(h)
+
+    def forward(t, mem_h, mem_c, training):
+        pairs, _, positive = tasks[t]
+        src, dst, n, feat, _ = dispatch(edges, nodes, n_timestamps, t)
+        keep = np.ones(len(src), dtype=bool)
+        keep[np.asarray(positive, dtype=np.int64)] = False
+        h = torch.tensor(np.asarray(feat, dtype=np.float32))
+        for w, b in convs_t:
+            h = graphconv_torch(src[keep], dst[keep], n, h, w, b, act="leaky_relu")
+        ids, pid = process_target_ids(np.asarray(pairs))
+        ids_t = torch.from_numpy(ids.astype(np.int64))
+        x = h[ids_t]
+        new_h, new_c = [], []
+        for k, layer in enumerate(rnn_t):
+            x, c = cell(x, mem_h[k, ids_t], None if mem_c is None else mem_c[k, ids_t], *layer)
+            new_h.append(x.detach())
+            new_c.append(None if c is None else c.detach())
+        if training:
+            for k in range(len(rnn_t)):
+                mem_h[k, ids_t] = new_h[k]
+                if mem_c is not None:
+                    mem_c[k, ids_t] = new_c[k]
+        z = x[torch.from_numpy(pid.reshape(-1).astype(np.int64))].reshape(pid.shape[0], -1)
+        return head(z, training).squeeze(-1)
+
+    def loss_of(p, label):
+        y = torch.tensor(np.asarray(label, dtype=np.float32))
+        if loss_order == "swapped":
+            yc = y.clamp(1e-7, 1 - 1e-7)
+            return -(p * torch.log(yc) + (1 - p) * torch.log(1 - yc)).mean()
+        return -(y * torch.log(p).clamp(min=-100) + (1 - y) * torch.log(1 - p).clamp(min=-100)).mean()
+
+    losses, first_grads = [], None
+    for _ in range(epochs):
+        mem_h = torch.tensor(np.asarray(mem_h0, dtype=np.float32))
+        mem_c = None if mem_c0 is None else torch.tensor(np.asarray(mem_c0, dtype=np.float32))
+        for t in train_ts:
+            opt.zero_grad()
+            loss = loss_of(forward(t, mem_h, mem_c, True), tasks[t][1])
+            loss.backward()
+            if first_grads is None:
+                first_grads = [q.grad.detach().numpy().copy() for q in params]
+            opt.step()
+            losses.append(float(loss.detach()))
+    with torch.no_grad():
+        predict = forward(eval_t, mem_h, mem_c, False).numpy()
+    n_pos = len(tasks[eval_t][2])
+    n_eval = n_pos // positives_per_node
+    neg = predict[n_pos:].reshape(n_eval, eval_negatives_per_node)
+    return {"losses": losses, "first_grads": first_grads,
+            "params": [q.detach().numpy() for q in params],
+            "eval_predict": predict, "eval_loss": float(loss_of(torch.from_numpy(predict), tasks[eval_t][1])),
+            "mrr": mrr_numpy(predict[:n_pos], np.repeat(neg, positives_per_node, axis=0)),
+            "mem_h": mem_h.numpy()}
+
+
 def neg_sampling(pos_inds, n_items, n_samp, rng=np.random):
     """spiro/core/dataio.py:29-35 (pos_inds sorted)."""
     pos_inds = np.asarray(pos_inds)

@@ -164,7 +164,14 @@ class SequentialDecoder(ops.WeightCacheHooks, nn.Module):
     def cuda(self, device=None):
         return self.to(torch.device("cuda" if device is None else device))
 
-    def training(self):  # noqa: D401  (reference name; shadows nn.Module.training on purpose)
+    def training(self):  # noqa: D401
+        """The reference's name for `train_mode` (implicitTimeModels.py:132-134).  On an instance
+        it is hidden by the boolean `training` attribute that torch.nn.Module sets, there as here,
+        so `decoder.training()` raises TypeError in both; call `train_mode()`."""
+        self.training_mode = True
+
+    def train_mode(self):
+        """Write the new state back to the node memory on every step (the default)."""
         self.training_mode = True
 
     def eval_mode(self):

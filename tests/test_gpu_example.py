@@ -65,3 +65,15 @@ def test_reference_script_idioms():
             loss.backward()
             optimizer.step()
         assert torch.isfinite(loss).item()
+
+
+LINK_SCRIPT = os.path.join(os.path.dirname(SCRIPT), "link_prediction.py")
+
+
+@pytest.mark.parametrize("extra", [[], ["--rnn", "lstm", "--gnn", "sage", "--reference-loss-order"]])
+def test_link_prediction_example_runs(monkeypatch, capsys, extra):
+    monkeypatch.setattr(sys, "argv", [LINK_SCRIPT, "--epochs", "2", "--nodes", "4000", "--edges", "50000",
+                                      "--steps", "8", "--start", "3", "--eval-negatives", "40"] + extra)
+    runpy.run_path(LINK_SCRIPT, run_name="__main__")
+    out = capsys.readouterr().out
+    assert "epoch 1: train loss" in out and "MRR" in out and "nan" not in out.lower()
