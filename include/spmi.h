@@ -89,6 +89,34 @@ int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*de
                     int32_t* status /*device [1]*/, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Snapshot build in one call: COO -> CSR, the normaliser of the key side and
+ * the load-balance plan of the aggregation.  Replaces the same reference
+ * lines as spmi_coo_to_csr (dgl.graph + COOToCSR, spiro/dtdg/types.py:191),
+ * spmi_norm_from_indptr (the in_degrees()/clamp/pow of dgl GraphConv.forward,
+ * call sites staticGraphEncoder.py:113,116) and spmi_spmm_plan together; the
+ * outputs are bit-identical to those three calls.  For 4096 < N <= 2^20 the
+ * edges take ONE stable radix pass on the top bits of the row id, after which
+ * every bucket of 4096 rows is contiguous and in edge order; the rest is a
+ * stable counting sort inside the buckets (segments of 8192 edges, wave-ballot
+ * ranking, writes inside a cache-resident window), whose workgroups also write
+ * row pointers, normaliser and hub rows: six launches and two passes over the
+ * edges instead of sixteen launches and four passes.  Other N run the three
+ * calls as they are.
+ *   norm_key  nullable, device [N]: f(row degree), mode as spmi_norm_from_indptr
+ *   meta      device int32[3], ZEROED BY THE CALLER: [0] status (non-zero: an
+ *             id outside its range, clamped), [1] hub rows, [2] chunks
+ *   heavy_*   as spmi_spmm_plan; the order of heavy_rows is not specified
+ * ---------------------------------------------------------------------- */
+size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N);
+int spmi_snapshot_csr(const int64_t* key /*device [E]*/, const int64_t* other /*device [E]*/,
+                      int64_t E, int64_t N /*key range*/, int64_t N_other /*other range*/,
+                      int32_t* indptr /*device [N+1]*/, int32_t* indices /*device [E]*/,
+                      int32_t* eid /*nullable, device [E]*/, float* norm_key /*nullable, device [N]*/,
+                      int norm_mode, int32_t heavy_thresh, int32_t chunk,
+                      int32_t* heavy_rows, int32_t* heavy_chunk_ptr, int64_t capacity, void* ws,
+                      size_t ws_bytes, int32_t* meta /*device [3], zeroed*/, void* stream);
+
+/* ------------------------------------------------------------------------
  * Cumulative snapshots.  Replaces the per-call rebuild of dgl.graph on the
  * slice `edges[:anchor[t]]` in VEInvariantDTDG.dispatcher
  * (spiro/dtdg/types.py:183-198) and the extra build of snapshot t-1 that

@@ -14,6 +14,8 @@
 // of the sorted keys as run boundaries, so degrees need no atomics either and
 // every output is bit-reproducible.  All of it is HBM-bound integer work.
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -70,6 +72,49 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
   *total = sum;
   __syncthreads();
   return base + incl - v;
+}
+
+// The lanes of this wave row whose (valid) digit equals this lane's, as two 32-bit halves,
+// and how many of them sit below this lane.  Per bit: one sign-extending bit-field extract
+// (0 or all ones), one compare for the ballot, and xnor + and per half; the ranking of a
+// radix pass is bound by exactly this vector work, not by memory.
+struct WaveMatch {
+  uint32_t lo, hi;      // lanes with the same digit
+  uint32_t below;       // ... of which below this lane
+  __device__ __forceinline__ uint32_t size() const { return __popc(lo) + __popc(hi); }
+};
+
+template <int BITS>
+__device__ __forceinline__ WaveMatch wave_match(uint32_t d, bool valid) {
+  // `d` must be 0 in lanes that are not valid (they then never raise a ballot bit)
+  const uint64_t v = __ballot(valid);
+  uint32_t diff_lo = 0, diff_hi = 0;   // lanes that differ from this one in some bit
+#pragma unroll
+  for (int bb = 0; bb < BITS; ++bb) {
+    int32_t m;                           // bit set: all ones, else 0
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(bb));
+    const uint64_t bal = __ballot(m != 0);
+    diff_lo |= static_cast<uint32_t>(bal) ^ static_cast<uint32_t>(m);
+    diff_hi |= static_cast<uint32_t>(bal >> 32) ^ static_cast<uint32_t>(m);
+  }
+  WaveMatch r;
+  r.lo = static_cast<uint32_t>(v) & ~diff_lo;
+  r.hi = static_cast<uint32_t>(v >> 32) & ~diff_hi;
+  r.below = __builtin_amdgcn_mbcnt_hi(r.hi, __builtin_amdgcn_mbcnt_lo(r.lo, 0u));
+  return r;
+}
+
+__device__ __forceinline__ WaveMatch wave_match_n(uint32_t d, bool valid, int bits) {
+  switch (bits) {   // uniform: a pass has one digit width
+    case 1: return wave_match<1>(d, valid);
+    case 2: return wave_match<2>(d, valid);
+    case 3: return wave_match<3>(d, valid);
+    case 4: return wave_match<4>(d, valid);
+    case 5: return wave_match<5>(d, valid);
+    case 6: return wave_match<6>(d, valid);
+    case 7: return wave_match<7>(d, valid);
+    default: return wave_match<8>(d, valid);
+  }
 }
 
 // ---- pass kernel 1: per-tile digit histogram ------------------------------------
@@ -201,7 +246,6 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
   uint32_t val0[kKeysPerThread];
   uint32_t val1[kKeysPerThread];
   uint32_t rank[kKeysPerThread];
-  const uint64_t lanes_below = (1ull << lane) - 1ull;
 
 #pragma unroll
   for (int j = 0; j < kKeysPerThread; ++j) {
@@ -218,17 +262,11 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
     val1[j] = b;
     const uint32_t d = (k >> shift) & mask;
     // lanes of this wave row that hold the same digit
-    uint64_t same = __ballot(valid);
-    for (int bb = 0; bb < bits; ++bb) {
-      const bool bit = (d >> bb) & 1u;
-      const uint64_t bal = __ballot(valid && bit);
-      same &= bit ? bal : ~bal;
-    }
-    const uint32_t below = __popcll(same & lanes_below);
+    const WaveMatch same = wave_match_n(d, valid, bits);
     uint32_t prev = 0;
     if (valid) prev = s_cnt[wave][d];
-    rank[j] = prev + below;
-    if (valid && below == 0) s_cnt[wave][d] = prev + static_cast<uint32_t>(__popcll(same));
+    rank[j] = prev + same.below;
+    if (valid && same.below == 0) s_cnt[wave][d] = prev + same.size();
   }
   __syncthreads();
 
@@ -277,6 +315,71 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
       keys_out[g] = k;
       if constexpr (NVAL >= 1) v0_out[g] = s_v0[i];
       if constexpr (NVAL >= 2) v1_out[g] = s_v1[i];
+    }
+  }
+}
+
+// ---- grouping without order -------------------------------------------------------------
+// Counting the ids of a bucket needs them side by side, in any order.  The same tile
+// histogram and scan as a sort pass give every (tile, digit) its run in the output; inside the
+// run a key takes the next free slot (an integer LDS counter per digit; the tile is staged in
+// LDS in digit order and written out run by run), so no ranking is needed, and ranking is what
+// a stable pass spends its time on.  Which key lands in which slot of its run varies from
+// launch to launch; the counts made from the result do not.
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void bucket_scatter_kernel(
+    const KeyT* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int64_t E, uint32_t N, int shift,
+    int bits, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, int n_tiles,
+    int32_t* status) {
+  __shared__ uint32_t s_cursor[kMaxDigits];
+  __shared__ uint32_t s_dstart[kMaxDigits];
+  __shared__ uint32_t s_goff[kMaxDigits];
+  __shared__ uint32_t s_wave[kWaves];
+  __shared__ uint32_t s_keys[kTile];
+  const int ndig = 1 << bits;
+  const uint32_t mask = ndig - 1;
+  const int tid = threadIdx.x;
+  if (tid < ndig) s_cursor[tid] = 0;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  const int64_t left = E - base;
+  const int tile_count = left < kTile ? static_cast<int>(left) : kTile;
+  KeyT raw[kKeysPerThread];
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = base + j * kThreads + tid;
+    raw[j] = keys_in[i < E ? i : E - 1];
+  }
+  __syncthreads();
+  uint32_t key[kKeysPerThread];
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    key[j] = 0;
+    if (j * kThreads + tid < tile_count) {
+      key[j] = checked_key(raw[j], N, status);
+      atomicAdd(&s_cursor[(key[j] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t unused;
+  const uint32_t dstart = block_exclusive_scan(tid < ndig ? s_cursor[tid] : 0u, s_wave, &unused);
+  const uint32_t gbase = block_exclusive_scan(tid < ndig ? totals[tid] : 0u, s_wave, &unused);
+  if (tid < ndig) {
+    s_dstart[tid] = dstart;
+    s_cursor[tid] = dstart;
+    s_goff[tid] = gbase + hist[static_cast<size_t>(tid) * n_tiles + blockIdx.x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j)
+    if (j * kThreads + tid < tile_count) s_keys[atomicAdd(&s_cursor[(key[j] >> shift) & mask], 1u)] = key[j];
+  __syncthreads();
+#pragma unroll 4
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int i = j * kThreads + tid;
+    if (i < tile_count) {
+      const uint32_t k = s_keys[i];
+      const uint32_t d = (k >> shift) & mask;
+      keys_out[s_goff[d] + (static_cast<uint32_t>(i) - s_dstart[d])] = k;
     }
   }
 }
@@ -472,6 +575,283 @@ __global__ __launch_bounds__(kPlanThreads) void plan_finish_kernel(
   }
 }
 
+// ---- bucket stage: stable grouping inside buckets of 4096 rows -----------------------------
+// After ONE stable scatter pass on the top bits of the row id the edges of a bucket of 4096
+// consecutive rows are contiguous and still in edge order.  What is left is a stable counting
+// sort on 12 bits inside every bucket, and that needs no further pass over the whole array:
+// a bucket is cut into segments of 8192 edges, one workgroup (four waves) each;
+//   seg_count_kernel   counts the rows of its segment in LDS and writes the 4096 counts
+//                      (16 bits each) as one row of a table;
+//   seg_place_kernel   adds up the table rows of its bucket (row totals -> row pointers, and
+//                      the counts of the segments in front of its own), ranks its 8192 edges
+//                      with wave ballots (stable) and writes every edge straight to its final
+//                      place.  The writes of a bucket fall into a window of a few hundred KB,
+//                      which the L2 holds; consecutive segments run on the same XCD.
+// The first segment of a bucket also writes the bucket's row pointers, its normaliser and its
+// rows above the hub threshold, so run boundaries, the normaliser pass and the hub-row scan of
+// the three-pass sort are gone with two of its three passes.
+constexpr int kLow = 12;
+constexpr int kRows = 1 << kLow;                  // rows per bucket
+constexpr int kRowWords = kRows / 2;              // a table row: 4096 16-bit counts in 2048 words
+constexpr int kSegThreads = 256;
+constexpr int kSegWaves = kSegThreads / 64;
+constexpr int kSegKeys = 32;                      // edges per thread
+constexpr int kSeg = kSegThreads * kSegKeys;      // edges per segment
+constexpr int kRowsPerThread = kRows / kSegThreads;   // 16 rows = 8 table words = 2 x 16 bytes
+constexpr int kMaxBuckets = 256;
+
+struct SegLoc {
+  int bucket, seg_in_bucket;
+  uint32_t n_seg, seg_base, bstart, bcount;
+};
+
+__device__ __forceinline__ uint32_t seg_block_scan(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+  const uint32_t incl = wave_inclusive_scan(v);
+  if (lane_id() == 63) s_wave[wave_id()] = incl;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kSegWaves; ++w) {
+    const uint32_t c = s_wave[w];
+    if (w < wave_id()) base += c;
+    sum += c;
+  }
+  *total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+
+// Which segment of which bucket this workgroup owns.  Every bucket has at least one segment
+// (an empty bucket still has row pointers to write).  Workgroup numbers are dealt so that
+// consecutive segments run on one XCD (workgroups go round the 8 XCDs).  False: no such segment.
+__device__ __forceinline__ bool locate_segment(const uint32_t* __restrict__ totals, int n_buckets, int grid,
+                                               SegLoc* s_loc, uint32_t* s_wave) {
+  const int seg = static_cast<int>(blockIdx.x & 7) * (grid >> 3) + static_cast<int>(blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const uint32_t cnt = tid < n_buckets ? totals[tid] : 0u;
+  const uint32_t segs = tid < n_buckets ? max(1u, (cnt + kSeg - 1) / kSeg) : 0u;
+  uint32_t total_cnt, total_segs;
+  const uint32_t bstart = seg_block_scan(cnt, s_wave, &total_cnt);
+  const uint32_t sbase = seg_block_scan(segs, s_wave, &total_segs);
+  if (tid < n_buckets && static_cast<uint32_t>(seg) >= sbase && static_cast<uint32_t>(seg) < sbase + segs) {
+    s_loc->bucket = tid;
+    s_loc->seg_in_bucket = seg - static_cast<int>(sbase);
+    s_loc->n_seg = segs;
+    s_loc->seg_base = sbase;
+    s_loc->bstart = bstart;
+    s_loc->bcount = cnt;
+  }
+  __syncthreads();
+  return static_cast<uint32_t>(seg) < total_segs;
+}
+
+__global__ __launch_bounds__(kSegThreads) void seg_count_kernel(const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ totals,
+                                                                int n_buckets, int grid,
+                                                                uint32_t* __restrict__ table) {
+  __shared__ uint32_t s_hist[kRowWords];
+  __shared__ uint32_t s_wave[kSegWaves];
+  __shared__ SegLoc s_loc;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < kRowWords / kSegThreads; ++i) s_hist[i * kSegThreads + tid] = 0;
+  if (!locate_segment(totals, n_buckets, grid, &s_loc, s_wave)) return;
+  const SegLoc L = s_loc;
+  const uint32_t lo = L.bstart + static_cast<uint32_t>(L.seg_in_bucket) * kSeg;
+  const uint32_t hi = min(lo + kSeg, L.bstart + L.bcount);
+  uint32_t k[kSegKeys];
+#pragma unroll
+  for (int j = 0; j < kSegKeys; ++j) {
+    const uint32_t i = lo + j * kSegThreads + tid;
+    k[j] = i < hi ? keys[i] : 0xffffffffu;
+  }
+#pragma unroll
+  for (int j = 0; j < kSegKeys; ++j) {
+    if (k[j] != 0xffffffffu) {
+      const uint32_t r = k[j] & (kRows - 1);
+      atomicAdd(&s_hist[r >> 1], 1u << (16 * (r & 1)));   // at most 8192 per half: no carry
+    }
+  }
+  __syncthreads();
+  uint4* row = reinterpret_cast<uint4*>(table + static_cast<size_t>(L.seg_base + L.seg_in_bucket) * kRowWords);
+#pragma unroll
+  for (int i = 0; i < kRowWords / 4 / kSegThreads; ++i)
+    row[i * kSegThreads + tid] = reinterpret_cast<const uint4*>(s_hist)[i * kSegThreads + tid];
+}
+
+template <int NVAL>
+__global__ __launch_bounds__(kSegThreads) void seg_place_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ v0_in, const uint32_t* __restrict__ v1_in,
+    const uint32_t* __restrict__ totals, int n_buckets, int grid, const uint32_t* __restrict__ table,
+    int64_t E, int64_t N, int32_t* __restrict__ indptr, uint32_t* __restrict__ v0_out,
+    uint32_t* __restrict__ v1_out, float* __restrict__ norm, int mode, int32_t heavy_thresh,
+    int32_t* __restrict__ heavy_rows, int64_t capacity, int32_t* counts) {
+  __shared__ __align__(16) uint16_t s_cnt[kSegWaves][kRows];
+  __shared__ __align__(16) uint32_t s_off[kRows];
+  __shared__ uint32_t s_wave[kSegWaves];
+  __shared__ SegLoc s_loc;
+  __shared__ int32_t s_base;
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const int wave = wave_id();
+  {
+    uint4* z = reinterpret_cast<uint4*>(&s_cnt[0][0]);
+#pragma unroll
+    for (int i = 0; i < static_cast<int>(sizeof(s_cnt) / 16) / kSegThreads; ++i)
+      z[i * kSegThreads + tid] = make_uint4(0, 0, 0, 0);
+  }
+  if (!locate_segment(totals, n_buckets, grid, &s_loc, s_wave)) return;
+  const SegLoc L = s_loc;
+  const uint32_t lo = L.bstart + static_cast<uint32_t>(L.seg_in_bucket) * kSeg;
+  const uint32_t hi = min(lo + kSeg, L.bstart + L.bcount);
+
+  // this thread's edges: a wave owns 2048 consecutive edges, 64 at a time (edge order)
+  uint32_t key[kSegKeys];
+#pragma unroll
+  for (int g = 0; g < kSegKeys; ++g) {
+    const uint32_t i = lo + wave * (64 * kSegKeys) + g * 64 + lane;
+    key[g] = i < hi ? keys[i] : 0u;
+  }
+
+  // rows 16 tid .. 16 tid + 15 of the bucket: totals over all its segments, and over those in
+  // front of this one (four table rows in flight at a time)
+  constexpr int R = kRowsPerThread;
+  uint32_t tot[R], bef[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) tot[i] = bef[i] = 0;
+  const uint4* rows = reinterpret_cast<const uint4*>(table + static_cast<size_t>(L.seg_base) * kRowWords) + 2 * tid;
+  for (uint32_t q0 = 0; q0 < L.n_seg; q0 += 4) {
+    uint4 w[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t q = min(q0 + u, L.n_seg - 1);
+      w[u][0] = rows[static_cast<size_t>(q) * (kRowWords / 4)];
+      w[u][1] = rows[static_cast<size_t>(q) * (kRowWords / 4) + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q0 + u < L.n_seg) {
+        const uint32_t c[8] = {w[u][0].x, w[u][0].y, w[u][0].z, w[u][0].w, w[u][1].x, w[u][1].y, w[u][1].z, w[u][1].w};
+        const bool front = q0 + u < static_cast<uint32_t>(L.seg_in_bucket);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t c_lo = c[i] & 0xffffu, c_hi = c[i] >> 16;
+          tot[2 * i] += c_lo;
+          tot[2 * i + 1] += c_hi;
+          if (front) {
+            bef[2 * i] += c_lo;
+            bef[2 * i + 1] += c_hi;
+          }
+        }
+      }
+    }
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) sum += tot[i];
+  uint32_t unused;
+  uint32_t run = L.bstart + seg_block_scan(sum, s_wave, &unused);
+  const bool first_seg = L.seg_in_bucket == 0;   // uniform over the workgroup
+  const int64_t row0 = (static_cast<int64_t>(L.bucket) << kLow) + R * tid;
+  uint32_t flags = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    s_off[R * tid + i] = run + bef[i];
+    if (first_seg) {
+      // row pointers, normaliser and hub rows of this bucket
+      const int64_t r = row0 + i;
+      if (r < N) {
+        indptr[r] = static_cast<int32_t>(run);
+        if (norm) {
+          const float d = fmaxf(static_cast<float>(tot[i]), 1.0f);
+          norm[r] = (mode == SPMI_NORM_RSQRT) ? (1.0f / sqrtf(d)) : (1.0f / d);
+        }
+        if (heavy_rows && static_cast<int32_t>(tot[i]) > heavy_thresh) flags |= 1u << i;
+      }
+    }
+    run += tot[i];
+  }
+  if (first_seg) {
+    if (L.bucket == n_buckets - 1 && tid == 0) indptr[N] = static_cast<int32_t>(E);
+    if (heavy_rows) {
+      uint32_t total;
+      const uint32_t ex = seg_block_scan(static_cast<uint32_t>(__popc(flags)), s_wave, &total);
+      if (total) {
+        if (tid == 0) s_base = atomicAdd(&counts[0], static_cast<int32_t>(total));
+        __syncthreads();
+        int64_t pos = static_cast<int64_t>(s_base) + ex;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          if (flags & (1u << i)) {
+            if (pos < capacity) heavy_rows[pos] = static_cast<int32_t>(row0 + i);
+            ++pos;
+          }
+        }
+      }
+    }
+  }
+
+  // rank inside the wave's 2048 edges: same row, earlier position (ballots: stable, no atomics).
+  // From here on key[g] holds (row inside the bucket) | (rank << 12).
+#pragma unroll
+  for (int g = 0; g < kSegKeys; ++g) {
+    const uint32_t i = lo + wave * (64 * kSegKeys) + g * 64 + lane;
+    const bool valid = i < hi;
+    const uint32_t d = key[g] & (kRows - 1);
+    const WaveMatch same = wave_match<kLow>(d, valid);
+    uint32_t prev = 0;
+    if (valid) prev = s_cnt[wave][d];
+    key[g] = d | ((prev + same.below) << kLow);
+    if (valid && same.below == 0) s_cnt[wave][d] = static_cast<uint16_t>(prev + same.size());
+  }
+  // the values that travel with the edges: fetched now, so that they arrive under the scan
+  // below (holding them from the start costs a third of the kernel's registers)
+  uint32_t val0[kSegKeys], val1[kSegKeys];
+#pragma unroll
+  for (int g = 0; g < kSegKeys; ++g) {
+    const uint32_t i = lo + wave * (64 * kSegKeys) + g * 64 + lane;
+    const bool valid = i < hi;
+    if constexpr (NVAL >= 1) val0[g] = valid ? v0_in[i] : 0u;
+    if constexpr (NVAL >= 2) val1[g] = valid ? v1_in[i] : 0u;
+  }
+  __syncthreads();
+  // per row: counts of the waves -> offsets of the waves (a wave's edges follow those of the
+  // waves below it)
+  {
+    uint32_t acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0;
+#pragma unroll
+    for (int w = 0; w < kSegWaves; ++w) {
+      uint4* p = reinterpret_cast<uint4*>(&s_cnt[w][R * tid]);
+#pragma unroll
+      for (int h = 0; h < R / 8; ++h) {
+        const uint4 c = p[h];
+        const uint32_t v[4] = {c.x, c.y, c.z, c.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = acc[8 * h + 2 * i] | (acc[8 * h + 2 * i + 1] << 16);
+          acc[8 * h + 2 * i] += v[i] & 0xffffu;
+          acc[8 * h + 2 * i + 1] += v[i] >> 16;
+        }
+        p[h] = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < kSegKeys; ++g) {
+    const uint32_t i = lo + wave * (64 * kSegKeys) + g * 64 + lane;
+    if (i < hi) {
+      const uint32_t d = key[g] & (kRows - 1);
+      const uint32_t pos = s_off[d] + s_cnt[wave][d] + (key[g] >> kLow);
+      if constexpr (NVAL >= 1) v0_out[pos] = val0[g];
+      if constexpr (NVAL >= 2) v1_out[pos] = val1[g];
+    }
+  }
+}
+
 // ---- host-side sort driver ------------------------------------------------------------
 struct SortShape {
   int passes;
@@ -597,6 +977,104 @@ int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t
   return SPMI_OK;
 }
 
+// True when the one-pass + bucket-stage build applies: more than one bucket of 4096 rows and
+// at most 256 of them (the pass on the top bits has digits of at most 8 bits).
+static bool bucket_build_applies(int64_t E, int64_t N) {
+  return E > 0 && N > kRows && N <= (static_cast<int64_t>(kMaxBuckets) << kLow);
+}
+
+static int bucket_build_grid(int64_t E, int n_buckets) {
+  const int64_t segs = (E + kSeg - 1) / kSeg + n_buckets;
+  return static_cast<int>((segs + 7) / 8 * 8);
+}
+
+size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 1) return 0;
+  size_t bytes = spmi_coo_to_csr_workspace_bytes(E, N);
+  if (bucket_build_applies(E, N)) {
+    const int n_buckets = static_cast<int>((N + kRows - 1) >> kLow);
+    const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+    const size_t table = sizeof(uint32_t) * kRowWords * (size_t)bucket_build_grid(E, n_buckets);
+    bytes = std::max(bytes, 3 * e4 + sort_scratch_bytes(E, N) + table);
+  }
+  return bytes;
+}
+
+int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N, int64_t N_other,
+                      int32_t* indptr, int32_t* indices, int32_t* eid, float* norm_key, int norm_mode,
+                      int32_t heavy_thresh, int32_t chunk, int32_t* heavy_rows, int32_t* heavy_chunk_ptr,
+                      int64_t capacity, void* ws, size_t ws_bytes, int32_t* meta, void* stream) {
+  if (int rc = check_sizes(E, N, "spmi_snapshot_csr")) return rc;
+  SPMI_REQUIRE(meta && indptr, SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: null indptr/meta");
+  SPMI_REQUIRE(!norm_key || norm_mode == SPMI_NORM_RSQRT || norm_mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
+               "spmi_snapshot_csr: bad norm_mode %d", norm_mode);
+  SPMI_REQUIRE(heavy_rows && heavy_chunk_ptr && heavy_thresh >= 1 && chunk >= 1 && capacity >= 2,
+               SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: bad plan arguments");
+  SPMI_REQUIRE(ws_bytes >= spmi_snapshot_csr_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
+               "spmi_snapshot_csr: workspace %zu < required %zu", ws_bytes,
+               spmi_snapshot_csr_workspace_bytes(E, N));
+  hipStream_t st = spmi::as_stream(stream);
+  if (!bucket_build_applies(E, N)) {
+    // a single bucket, or more than 256 of them: the three-pass sort and its separate kernels
+    if (int rc = spmi_coo_to_csr(key, other, E, N, N_other, indptr, indices, eid, ws, ws_bytes, meta, stream))
+      return rc;
+    if (norm_key)
+      if (int rc = spmi_norm_from_indptr(indptr, N, norm_mode, norm_key, stream)) return rc;
+    return spmi_spmm_plan(indptr, N, heavy_thresh, chunk, heavy_rows, heavy_chunk_ptr, capacity, meta + 1,
+                          stream);
+  }
+  SPMI_REQUIRE(N_other >= 1 && N_other < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG,
+               "spmi_snapshot_csr: bad N_other=%lld", (long long)N_other);
+  SPMI_REQUIRE(key && other && indices && ws, SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: null pointer argument");
+  int bits = 1;
+  while ((int64_t{1} << bits) < N) ++bits;
+  const int top = bits - kLow;                      // 1..8
+  const int n_buckets = static_cast<int>((N + kRows - 1) >> kLow);
+  const int n_tiles = static_cast<int>((E + kTile - 1) / kTile);
+  const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
+  char* p = static_cast<char*>(ws);
+  uint32_t* keys_b = reinterpret_cast<uint32_t*>(p);
+  uint32_t* v0_b = reinterpret_cast<uint32_t*>(p + e4);
+  uint32_t* v1_b = reinterpret_cast<uint32_t*>(p + 2 * e4);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(p + 3 * e4);
+  const size_t hist_bytes = spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)n_tiles, 256);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(p + 3 * e4 + hist_bytes);
+  uint32_t* table = reinterpret_cast<uint32_t*>(p + 3 * e4 + sort_scratch_bytes(E, N));
+  int32_t* status = meta;
+  const dim3 grid(n_tiles), block(kThreads);
+  radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(key, E, (uint32_t)N, kLow, top, hist, n_tiles, status);
+  SPMI_CHECK_LAUNCH("radix_hist(bucket)");
+  radix_scan_kernel<<<dim3(1 << top), block, 0, st>>>(hist, n_tiles, totals);
+  SPMI_CHECK_LAUNCH("radix_scan(bucket)");
+  if (eid) {
+    radix_scatter_kernel<int64_t, true, 2><<<grid, block, 0, st>>>(
+        key, other, nullptr, nullptr, keys_b, v0_b, v1_b, E, (uint32_t)N, (uint32_t)N_other, kLow, top,
+        hist, totals, n_tiles, status);
+  } else {
+    radix_scatter_kernel<int64_t, true, 1><<<grid, block, 0, st>>>(
+        key, other, nullptr, nullptr, keys_b, v0_b, nullptr, E, (uint32_t)N, (uint32_t)N_other, kLow, top,
+        hist, totals, n_tiles, status);
+  }
+  SPMI_CHECK_LAUNCH("radix_scatter(bucket)");
+  const int sgrid = bucket_build_grid(E, n_buckets);
+  seg_count_kernel<<<sgrid, kSegThreads, 0, st>>>(keys_b, totals, n_buckets, sgrid, table);
+  SPMI_CHECK_LAUNCH("seg_count");
+  if (eid) {
+    seg_place_kernel<2><<<sgrid, kSegThreads, 0, st>>>(
+        keys_b, v0_b, v1_b, totals, n_buckets, sgrid, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices),
+        reinterpret_cast<uint32_t*>(eid), norm_key, norm_mode, heavy_thresh, heavy_rows, capacity - 1, meta + 1);
+  } else {
+    seg_place_kernel<1><<<sgrid, kSegThreads, 0, st>>>(
+        keys_b, v0_b, nullptr, totals, n_buckets, sgrid, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices),
+        nullptr, norm_key, norm_mode, heavy_thresh, heavy_rows, capacity - 1, meta + 1);
+  }
+  SPMI_CHECK_LAUNCH("seg_place");
+  plan_finish_kernel<<<1, kPlanThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr, capacity - 1,
+                                             meta + 1);
+  SPMI_CHECK_LAUNCH("plan_finish(bucket)");
+  return SPMI_OK;
+}
+
 size_t spmi_degree_workspace_bytes(int64_t E, int64_t N) {
   if (E < 0 || N < 1) return 0;
   const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
@@ -639,10 +1117,9 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
     SPMI_CHECK_LAUNCH("radix_hist(degree)");
     radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
     SPMI_CHECK_LAUNCH("radix_scan(degree)");
-    radix_scatter_kernel<int64_t, true, 0><<<grid, block, 0, st>>>(
-        ids, nullptr, nullptr, nullptr, b.keys[0], nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow,
-        bits, b.hist, b.totals, sh.n_tiles, status);
-    SPMI_CHECK_LAUNCH("radix_scatter(degree)");
+    bucket_scatter_kernel<int64_t><<<grid, block, 0, st>>>(ids, b.keys[0], E, (uint32_t)N, kCountLow, bits,
+                                                           b.hist, b.totals, sh.n_tiles, status);
+    SPMI_CHECK_LAUNCH("bucket_scatter(degree)");
     bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, nullptr, 0);
     SPMI_CHECK_LAUNCH("bucket_count");
     return SPMI_OK;
@@ -690,10 +1167,9 @@ int spmi_norm_from_ids32(const int32_t* ids, int64_t E, int64_t N, int mode, flo
     SPMI_CHECK_LAUNCH("radix_hist(ids32)");
     radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
     SPMI_CHECK_LAUNCH("radix_scan(ids32)");
-    radix_scatter_kernel<uint32_t, false, 0><<<grid, block, 0, st>>>(
-        keys, nullptr, nullptr, nullptr, b.keys[0], nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow,
-        bits, b.hist, b.totals, sh.n_tiles, no_status);
-    SPMI_CHECK_LAUNCH("radix_scatter(ids32)");
+    bucket_scatter_kernel<uint32_t><<<grid, block, 0, st>>>(keys, b.keys[0], E, (uint32_t)N, kCountLow, bits,
+                                                            b.hist, b.totals, sh.n_tiles, no_status);
+    SPMI_CHECK_LAUNCH("bucket_scatter(ids32)");
     bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, norm, mode);
     SPMI_CHECK_LAUNCH("bucket_count(ids32)");
     return SPMI_OK;

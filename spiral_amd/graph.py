@@ -64,6 +64,7 @@ class CSR:
         self._bad_ids = False
         self._pending = pending  # (pinned int32[3], event, device int32[3]) until ready()
         self._partial: Dict[int, torch.Tensor] = {}
+        self._norms: Dict[int, torch.Tensor] = {}  # normaliser of the rows, per mode
 
     def ready(self) -> "CSR":
         if self._pending is not None:
@@ -99,9 +100,12 @@ class CSR:
         return (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
 
     def norm(self, mode: int) -> torch.Tensor:
-        out = torch.empty(self.n_rows, dtype=torch.float32, device=self.indptr.device)
-        nv.check(nv.lib().spmi_norm_from_indptr(nv.ptr(self.indptr), self.n_rows, mode,
-                                                nv.ptr(out), nv.stream()), "spmi_norm_from_indptr")
+        out = self._norms.get(mode)
+        if out is None:
+            out = torch.empty(self.n_rows, dtype=torch.float32, device=self.indptr.device)
+            nv.check(nv.lib().spmi_norm_from_indptr(nv.ptr(self.indptr), self.n_rows, mode,
+                                                    nv.ptr(out), nv.stream()), "spmi_norm_from_indptr")
+            self._norms[mode] = out
         return out
 
 
@@ -145,11 +149,12 @@ def _fetch_meta(meta: torch.Tensor):
 
 def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
-              want_eid: bool = False, defer: bool = False) -> CSR:
-    """COO -> CSR grouped by `key` plus the aggregation plan.  The status word and the plan
-    sizes cost one host sync: here, or with `defer` at the CSR's first `ready()`.  Edge ids
-    travel through the sort only when `want_eid` (edge weights / edge features need them;
-    plain GCN does not)."""
+              want_eid: bool = False, defer: bool = False, norm_mode: Optional[int] = None) -> CSR:
+    """COO -> CSR grouped by `key` plus the aggregation plan, one library call.  The status word
+    and the plan sizes cost one host sync: here, or with `defer` at the CSR's first `ready()`.
+    Edge ids travel through the sort only when `want_eid` (edge weights / edge features need
+    them; plain GCN does not).  `norm_mode` (0 or 1): the normaliser of the key side is written
+    by the same kernels that write the row pointers and kept on the CSR (`CSR.norm(mode)`)."""
     nv.require_cuda(key, other)
     key, other = _i64(key).contiguous(), _i64(other).contiguous()
     dev = key.device
@@ -159,16 +164,23 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
         indptr = torch.empty(n_key + 1, dtype=torch.int32, device=dev)
         indices = torch.empty(e, dtype=torch.int32, device=dev)
         eid = torch.empty(e, dtype=torch.int32, device=dev) if want_eid else None
+        norm = torch.empty(n_key, dtype=torch.float32, device=dev) if norm_mode is not None else None
+        cap = e // heavy_thresh + 2
+        heavy_rows = torch.empty(cap, dtype=torch.int32, device=dev)
+        heavy_ptr = torch.empty(cap, dtype=torch.int32, device=dev)
         meta = _zeroed_meta(dev)  # status, n_heavy, n_chunks
-        ws_bytes = lib.spmi_coo_to_csr_workspace_bytes(e, n_key)
+        ws_bytes = lib.spmi_snapshot_csr_workspace_bytes(e, n_key)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        nv.check(lib.spmi_coo_to_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
-                                     nv.ptr(indices), nv.ptr(eid), nv.ptr(ws), ws_bytes,
-                                     nv.ptr(meta), nv.stream()), "spmi_coo_to_csr")
-        heavy_rows, heavy_ptr = _plan(indptr, n_key, e, meta, heavy_thresh, chunk)
+        nv.check(lib.spmi_snapshot_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
+                                       nv.ptr(indices), nv.ptr(eid), nv.ptr(norm),
+                                       0 if norm_mode is None else int(norm_mode), heavy_thresh, chunk,
+                                       nv.ptr(heavy_rows), nv.ptr(heavy_ptr), cap, nv.ptr(ws), ws_bytes,
+                                       nv.ptr(meta), nv.stream()), "spmi_snapshot_csr")
         pending = _fetch_meta(meta)
     csr = CSR(indptr, indices, eid, n_key, n_other, e, heavy_rows, heavy_ptr, 0, 0, heavy_thresh,
               chunk, pending)
+    if norm is not None:
+        csr._norms[int(norm_mode)] = norm
     return csr if defer else csr.ready()
 
 
@@ -516,8 +528,10 @@ class SnapshotGraph(NormalisedAdjacency):
                 self._csr = self._table.by_dst().prefix(self._src.numel(), self._n, self._n, want_eid,
                                                         defer=True)
             else:
+                # GraphConv's default norm ('both') wants degree^-1/2 of the rows: written by the
+                # kernels that write the row pointers, for nothing
                 self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid,
-                                      defer=True)
+                                      defer=True, norm_mode=0)
         return self._csr.ready() if wait else self._csr
 
     def csr_t(self, want_eid: bool = False, wait: bool = True) -> CSR:
@@ -527,7 +541,7 @@ class SnapshotGraph(NormalisedAdjacency):
                                                           want_eid, defer=True)
             else:
                 self._csr_t = build_csr(self._src, self._dst, self._n, self._n, want_eid=want_eid,
-                                        defer=True)
+                                        defer=True, norm_mode=0)
         return self._csr_t.ready() if wait else self._csr_t
 
     def norm(self, side: str, mode: int) -> torch.Tensor:

@@ -168,3 +168,77 @@ def test_normaliser_from_a_32_bit_id_column(dev, n, e, mode):
     nv.check(lib.spmi_norm_from_ids32(nv.ptr(t), e, n, mode, nv.ptr(out), nv.ptr(deg), nv.ptr(ws), nbytes,
                                       nv.stream()), "spmi_norm_from_ids32")
     assert np.array_equal(deg.cpu().numpy(), want_deg) and torch.equal(out, want)
+
+
+def _old_three_calls(key, other, n, n_other, want_eid, mode, dev):
+    """spmi_coo_to_csr + spmi_norm_from_indptr + spmi_spmm_plan, the calls the one-call build
+    must reproduce bit for bit."""
+    lib = nv.lib()
+    e = key.numel()
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    indices = torch.empty(e, dtype=torch.int32, device=dev)
+    eid = torch.empty(e, dtype=torch.int32, device=dev) if want_eid else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.spmi_coo_to_csr_workspace_bytes(e, n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    nv.check(lib.spmi_coo_to_csr(nv.ptr(key), nv.ptr(other), e, n, n_other, nv.ptr(indptr), nv.ptr(indices),
+                                 nv.ptr(eid), nv.ptr(ws), ws_bytes, nv.ptr(status), nv.stream()), "coo_to_csr")
+    norm = torch.empty(n, dtype=torch.float32, device=dev)
+    nv.check(lib.spmi_norm_from_indptr(nv.ptr(indptr), n, mode, nv.ptr(norm), nv.stream()), "norm")
+    cap = e // G.HEAVY_THRESH + 2
+    rows = torch.empty(cap, dtype=torch.int32, device=dev)
+    ptr = torch.empty(cap, dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    nv.check(lib.spmi_spmm_plan(nv.ptr(indptr), n, G.HEAVY_THRESH, G.HEAVY_CHUNK, nv.ptr(rows), nv.ptr(ptr), cap,
+                                nv.ptr(counts), nv.stream()), "plan")
+    return indptr, indices, eid, norm, rows, ptr, counts.tolist(), int(status.item())
+
+
+@pytest.mark.parametrize("n,e,k_dst,mode", [(4097, 30_000, 3.0, 0), (5000, 8192, 1.0, 1), (70_000, 400_001, 3.0, 0),
+                                            (300_000, 2_000_000, 6.0, 0), (1 << 20, 3_000_000, 3.0, 1),
+                                            (1_000_000, 10_000_000, 3.0, 0), (200_000, 1_000_000, 40.0, 0)])
+def test_one_call_build_equals_the_three_calls(dev, n, e, k_dst, mode):
+    """spmi_snapshot_csr on its bucket path (4096 < N <= 2^20: one radix pass + the sort inside
+    buckets of 4096 rows) against the three-pass sort, the normaliser kernel and the plan
+    kernels: row pointers, column ids, edge ids and the normaliser bit for bit, the same set of
+    hub rows with the same chunk counts (their order is free).  k_dst = 40 puts most edges on a
+    handful of rows (buckets of many segments, empty buckets beside them)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(n + e)
+    perm = torch.randperm(n, generator=gen, device=dev)
+    dst = perm[(torch.rand(e, generator=gen, device=dev, dtype=torch.float64).pow_(k_dst) * n).long().clamp_(max=n - 1)]
+    src = perm[(torch.rand(e, generator=gen, device=dev, dtype=torch.float64).pow_(1.5) * n).long().clamp_(max=n - 1)]
+    for want_eid in (False, True):
+        indptr, indices, eid, norm, rows, ptr, counts, status = _old_three_calls(dst, src, n, n, want_eid, mode, dev)
+        assert status == 0
+        csr = G.build_csr(dst, src, n, n, want_eid=want_eid, norm_mode=mode)
+        assert torch.equal(csr.indptr, indptr) and torch.equal(csr.indices, indices)
+        assert (csr.eid is None) == (not want_eid) and (eid is None or torch.equal(csr.eid, eid))
+        assert torch.equal(csr.norm(mode), norm)
+        assert [csr.n_heavy, csr.n_chunks] == counts
+        nh = counts[0]
+        got = torch.sort(csr.heavy_rows[:nh])
+        want = torch.sort(rows[:nh])
+        assert torch.equal(got.values, want.values)
+        chunks = lambda p: (p[1: nh + 1] - p[:nh]) if nh else p[:0]
+        assert torch.equal(chunks(csr.heavy_chunk_ptr)[got.indices], chunks(ptr)[want.indices])
+        assert int(csr.heavy_chunk_ptr[nh]) == counts[1]
+    if e <= 3_000_000:   # and the oracle itself
+        ip, ix, ei = orc.coo_to_csr(dst.cpu().numpy(), src.cpu().numpy(), n)
+        assert np.array_equal(csr.indptr.cpu().numpy(), ip) and np.array_equal(csr.indices.cpu().numpy(), ix)
+        assert np.array_equal(csr.eid.cpu().numpy(), ei)
+
+
+def test_one_call_build_reports_bad_ids_and_runs_twice(dev):
+    n = 10_000
+    dst = torch.randint(0, n, (50_000,), device=dev)
+    src = torch.randint(0, n, (50_000,), device=dev)
+    bad = dst.clone()
+    bad[123] = n
+    with pytest.raises(nv.SpmiError):
+        G.build_csr(bad, src, n, n)
+    with pytest.raises(nv.SpmiError):
+        G.build_csr(src, bad, n, n)          # bad id on the `other` side
+    a = G.build_csr(dst, src, n, n, want_eid=True, norm_mode=0)
+    b = G.build_csr(dst, src, n, n, want_eid=True, norm_mode=0)
+    assert torch.equal(a.indices, b.indices) and torch.equal(a.eid, b.eid) and torch.equal(a.norm(0), b.norm(0))
