@@ -133,19 +133,25 @@ from spiral_amd.dtdg.types import identity_ids  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak of the part (no sparsity)
+MFMA_F16_MEASURED_TFLOPS = 1580.0  # bare v_mfma_f32_32x32x16_f16 stream, random operands (scripts/probe/mfma_rate.hip)
 HEAD_DIMS = [10, 20, 10, 5]  # the MLP of examples/torch/citation_prediction.py:73
 CPU_SAMPLE_DIV = 4      # the CPU baseline runs a snapshot of 1/4 of the nodes and edges
 
 
 def measured_traffic(workload: str, world: int, widths=None):
-    """HBM-side bytes per fused-aggregation launch group from the committed rocprofv3 PMC runs
-    of the same workload and kernel (FETCH_SIZE / WRITE_SIZE in separate passes, read side
-    calibrated on a copy of known size: profiles/*_spmm_traffic.json, newest first).  Counters
-    cannot be read from inside this process; a workload without a committed run reports null."""
+    """(HBM-side bytes per fused-aggregation launch group, whether the record was collected on the
+    kernel source this tree holds) from the committed rocprofv3 PMC runs of the same workload
+    (FETCH_SIZE / WRITE_SIZE in separate passes, read side calibrated on a copy of known size:
+    profiles/*_spmm_traffic.json, newest first; a record carries the sha256 of csrc/spmm.hip).
+    Counters cannot be read from inside this process; a workload without a committed run
+    reports (None, None)."""
     import glob
+    import hashlib
 
     if world != 1:
-        return None
+        return None, None
+    with open(os.path.join(ROOT, "spiral_amd", "csrc", "spmm.hip"), "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_spmm_traffic.json")), reverse=True):
         with open(path) as fh:
             rec = json.load(fh)
@@ -153,8 +159,8 @@ def measured_traffic(workload: str, world: int, widths=None):
             continue
         if widths is not None and widths != [rec.get("feature_width", 128)]:
             continue  # the record prices one width; this run's launches mix several
-        return rec["traffic_bytes_per_launch"]
-    return None
+        return rec["traffic_bytes_per_launch"], rec.get("kernel_source_sha256") == sha
+    return None, None
 
 
 def aggregation_kernel_name(feat: int, bf16: bool) -> str:
@@ -731,6 +737,12 @@ def main():
         stages["recurrent_roofline"] = {"bound": "mfma", "algorithmic_flops": alg, "matrix_flops": 3.0 * alg,
                                         "achieved": tfs, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": tfs / MFMA_F16_PEAK_TFLOPS,
+                                        # the same time against the flops the reference's fp32 GRU does
+                                        "algorithmic_frac": tfs / 3.0 / MFMA_F16_PEAK_TFLOPS,
+                                        # what a bare fp16 matrix-instruction stream reaches on this part
+                                        # with real (non-zero) operands: profiles/r02d_mfma_rate.txt
+                                        "measured_matrix_ceiling": MFMA_F16_MEASURED_TFLOPS,
+                                        "frac_of_measured_ceiling": tfs / MFMA_F16_MEASURED_TFLOPS,
                                         "covers": "2 GRU layers (fp32 results from three fp16 plane products "
                                                   "per term: matrix_flops = 3 x algorithmic) + MLP head"}
 
@@ -775,6 +787,7 @@ def main():
             print(f"step {i:3d} gap_before={gap:8.3f} " + " ".join(f"{n}={v:7.3f}" for n, v in zip(stage_names, series)),
                   file=sys.stderr, flush=True)
     if rank == 0:
+        traffic, traffic_matches = (None, None) if train else measured_traffic(args.workload, world, widths)
         ms_per_step = elapsed * 1e3 / args.steps
         result = {
             "metric": "aggregated edges/sec per snapshot (whole node)",
@@ -823,7 +836,10 @@ def main():
             "exchange_stats": exchange_stats,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None if train else measured_traffic(args.workload, world, widths),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_kernel_matches": traffic_matches,
+                "traffic_note": "HBM-side bytes per launch group from the committed counter run of this workload "
+                                "(L2 <-> fabric requests: the 256 MB memory-side cache serves part of them, which "
+                                "is how the achieved figure can exceed what HBM alone streams, ~6.3 TB/s)",
                 "kernel": "; ".join(aggregation_kernel_name(fw, kind == "evolve_bf16") for fw in widths),
                 "feature_widths": widths,
                 "avg_launch_ms": spmm_avg_ms, "launches": len(spmm_ms),

@@ -245,7 +245,10 @@ int spmi_gcn_spmm_part(const int32_t* indptr, const int32_t* indices, int64_t n_
  * are bit-identical to spmi_gcn_spmm_ex.  n_chunks * F beyond SPMI_STATIC_PARTIAL_FLOATS
  * is rejected with SPMI_ERR_WORKSPACE.  Every call on one GPU shares that GPU's array:
  * two calls that overlap in time on one GPU (different streams or host threads) race;
- * calls queued on one stream are safe. */
+ * calls queued on one stream are safe.  The FIRST call on a device looks up the array's
+ * address, which may make the runtime load the library's code object (and with it the
+ * array's 16 MiB) at that moment: make it outside graph capture and before a region that
+ * must not allocate.  Every later call on that device touches no allocator. */
 #define SPMI_STATIC_PARTIAL_FLOATS (4 * 1024 * 1024)
 int spmi_gcn_spmm_static(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
                          int64_t n_src, int64_t E, const void* X, int x_dtype, int64_t ldx,
@@ -264,6 +267,13 @@ int spmi_gcn_spmm_static(const int32_t* indptr, const int32_t* indices, int64_t 
 int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld,
                       int act, float slope, float* gP /*[M,F] ld=F*/, float* gb /*nullable [F]*/,
                       void* stream);
+/* The same with a bias gradient that is the same bits on every launch: every slab of 512 rows
+ * leaves its column sums in the workspace and a second kernel adds the slabs in slab order
+ * (gb is written, not accumulated, and needs no zeroing).  Same reference lines. */
+size_t spmi_act_bias_bwd_workspace_bytes(int64_t M, int64_t F);
+int spmi_act_bias_bwd_ordered(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld,
+                              int act, float slope, float* gP, float* gb /*device [F]*/, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Recurrent cells, sequence length 1, batch = nodes.  Replace the pointwise

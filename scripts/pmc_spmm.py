@@ -20,9 +20,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from spiral_amd import graph as G  # noqa: E402
 from perf_spmm import powerlaw  # noqa: E402
 
-# usage: pmc_spmm.py [F] [k_dst]   (defaults 128, 3.0: the headline workload)
+# usage: pmc_spmm.py [F] [k_dst] [N] [E]   (defaults 128, 3.0, 1M, 10M: the headline workload)
 f = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 k_dst = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+e = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
 dev = torch.device("cuda:0")
 n_cal = 10_000_000 if f <= 128 else 5_000_000
 perm = torch.randperm(n_cal, device=dev)
@@ -33,7 +35,6 @@ out_cal = torch.empty(n_cal, f, device=dev)
 ew_cal = torch.ones(n_cal, device=dev)
 ds_cal = torch.ones(n_cal, device=dev)
 
-n, e = 1_000_000, 10_000_000
 src, dst = powerlaw(n, e, 0, k_dst, 1.5, dev)
 csr = G.build_csr(dst, src, n, n)
 csr_t = G.build_csr(src, dst, n, n)

@@ -1,7 +1,7 @@
 """profiles/r01_spmm_traffic.json from two `rocprofv3 --pmc` passes over scripts/pmc_spmm.py
 (FETCH_SIZE in one run, WRITE_SIZE in another):
 
-    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag] [workload] [F]
+    python scripts/spmm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag] [workload] [F] [N] [E]
 
 Launch groups alternate calibration / benchmark (three repetitions); a group is the stream
 kernel plus, when the graph has hub rows, the two heavy-row kernels.  The read counter is
@@ -11,9 +11,13 @@ import json
 import os
 import sys
 
-N, E = 1_000_000, 10_000_000
+import hashlib
+
 WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "config2"
 F = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+N = int(sys.argv[6]) if len(sys.argv) > 6 else 1_000_000
+E = int(sys.argv[7]) if len(sys.argv) > 7 else 10_000_000
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_CAL = 10_000_000 if F <= 128 else 5_000_000
 
 
@@ -41,9 +45,12 @@ def main():
     rf, wf = known_r / cal_r, known_w / cal_w
     algorithmic = E * (F * 4 + 4) + (N + 1) * 4 + 2 * N * 4 + N * F * 4 + F * 4
     doc = {
-        "workload": f"{WORKLOAD}: 1M nodes x 10M edges, F={F}, inference launch (no per-edge weight, destination "
+        "workload": f"{WORKLOAD}: {N} nodes x {E} edges, F={F}, inference launch (no per-edge weight, destination "
                     "scale + bias + leaky_relu fused), fp32",
-        "feature_width": F,
+        "feature_width": F, "nodes": N, "edges": E,
+        # the kernel source the counters were collected on: bench.py compares it with the tree's
+        "kernel_source": "spiral_amd/csrc/spmm.hip",
+        "kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, "spiral_amd", "csrc", "spmm.hip"), "rb").read()).hexdigest(),
         "calibration": {"graph": f"permutation graph, {N_CAL} rows, one neighbour each (every source row read once)",
                         "known_read_bytes": known_r, "fetch_size_bytes_raw": cal_r, "read_factor": rf,
                         "known_write_bytes": known_w, "write_size_bytes_raw": cal_w, "write_factor": wf},

@@ -7,6 +7,7 @@ HIP stream; torch's caching allocator owns all memory.
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import Optional
 
@@ -53,6 +54,9 @@ _SIGNATURES = {
                                      c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_int, c_i64, c_vp, c_vp,
                                      c_i32, c_i32, c_i32, c_i32, c_vp]),
     "spmi_act_bias_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp]),
+    "spmi_act_bias_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "spmi_act_bias_bwd_ordered": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_sz,
+                                          c_vp]),
     "spmi_gather_rows": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "spmi_gru_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
                                   c_vp, c_vp]),
@@ -164,3 +168,30 @@ def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
         if t is not None and not t.is_cuda:
             raise SpmiError(
                 "spiral_amd kernels run on the GPU only (got a CPU tensor); there is no CPU path")
+
+
+# ---- zeroed device words, without a fill per use ---------------------------------------------
+_slot_pools: dict = {}
+_slot_lock = threading.Lock()
+
+
+def zeroed_slot(device, width: int):
+    """`width` zeroed int32 device words for the stream that is current on `device`.
+
+    Kernels here report through a few words the caller has zeroed (status, plan sizes, the bit
+    pattern of a maximum).  A fill per use would be a launch of its own, so the words are slices
+    of a block of 256 that one fill zeroes.  That fill runs on the stream that was current when
+    the block was made, so a block only ever serves that stream: work queued on another stream
+    is not ordered behind the fill and takes a block of its own.  A slice is handed out once; a
+    block lives as long as one of its slices.  Safe to call from several threads."""
+    import torch
+
+    dev = torch.device(device)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, width)
+    with _slot_lock:
+        pool = _slot_pools.get(key)
+        if pool is None or pool[1] >= pool[0].shape[0]:
+            pool = _slot_pools[key] = [torch.zeros(256, width, dtype=torch.int32, device=dev), 0]
+        slot = pool[0][pool[1]]
+        pool[1] += 1
+    return slot

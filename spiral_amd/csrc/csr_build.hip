@@ -1139,7 +1139,7 @@ int spmi_norm_from_ids32(const int32_t* ids, int64_t E, int64_t N, int mode, flo
   SPMI_REQUIRE(norm, SPMI_ERR_INVALID_ARG, "spmi_norm_from_ids32: null norm");
   SPMI_REQUIRE(mode == SPMI_NORM_RSQRT || mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
                "spmi_norm_from_ids32: bad mode %d", mode);
-  SPMI_REQUIRE(E == 0 || (ids && ws), SPMI_ERR_INVALID_ARG, "spmi_norm_from_ids32: null pointer argument");
+  SPMI_REQUIRE(ws && (E == 0 || ids), SPMI_ERR_INVALID_ARG, "spmi_norm_from_ids32: null pointer argument");
   SPMI_REQUIRE(ws_bytes >= spmi_degree_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
                "spmi_norm_from_ids32: workspace %zu < required %zu", ws_bytes,
                spmi_degree_workspace_bytes(E, N));

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
                                                                 int64_t M, int F, int64_t ld,
                                                                 int act, float slope,
                                                                 float* __restrict__ gP,
-                                                                float* __restrict__ gb) {
+                                                                float* __restrict__ gb,
+                                                                float* __restrict__ partials) {
   __shared__ float s_col[kWavesPerBlock][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -369,12 +370,13 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
       col += g;
     }
   }
-  if (gb) {
+  if (gb || partials) {
     s_col[wave][lane] = col;
     __syncthreads();
     if (wave == 0 && f < F) {
       float sum = s_col[0][lane] + s_col[1][lane] + s_col[2][lane] + s_col[3][lane];
-      atomicAdd(&gb[f], sum);
+      if (partials) partials[static_cast<size_t>(blockIdx.x) * F + f] = sum;
+      else atomicAdd(&gb[f], sum);
     }
   }
 }
@@ -386,7 +388,8 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
                                                                    int64_t M, int F, int64_t ld,
                                                                    int act, float slope,
                                                                    float* __restrict__ gP,
-                                                                   float* __restrict__ gb) {
+                                                                   float* __restrict__ gb,
+                                                                   float* __restrict__ partials) {
   __shared__ float4 s_col[16][16];
   const int cg = threadIdx.x & 15;   // column group: columns f .. f + 3
   const int rl = threadIdx.x >> 4;   // 0 .. 15: rows rl, rl + 16, ...
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
       }
     }
   }
-  if (gb) {
+  if (gb || partials) {
     s_col[rl][cg] = col;
     __syncthreads();
     if (threadIdx.x < 64 && blockIdx.y * 64 + static_cast<int>(threadIdx.x) < F) {
@@ -427,9 +430,40 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
       float sum = 0.0f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) sum += flat[q * 64 + threadIdx.x];
-      atomicAdd(&gb[blockIdx.y * 64 + threadIdx.x], sum);
+      const int fc = blockIdx.y * 64 + static_cast<int>(threadIdx.x);
+      if (partials) partials[static_cast<size_t>(blockIdx.x) * F + fc] = sum;
+      else atomicAdd(&gb[fc], sum);
     }
   }
+}
+
+// gb[f] = sum over the row slabs of their column sums, in slab order: a wave owns a quarter
+// of the slabs and walks it front to back (lanes = columns), the four wave sums are added in
+// wave order.  No atomics: the same bits on every launch.
+__global__ __launch_bounds__(kThreads) void bias_grad_reduce_kernel(const float* __restrict__ partials,
+                                                                    int n_slabs, int F,
+                                                                    float* __restrict__ gb) {
+  __shared__ float s_col[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  const int per = (n_slabs + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int s0 = wave * per, s1 = min(s0 + per, n_slabs);
+  float sum = 0.0f;
+  if (f < F) {
+    int q = s0;
+    for (; q + 8 <= s1; q += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partials[static_cast<size_t>(q + u) * F + f];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; q < s1; ++q) sum += partials[static_cast<size_t>(q) * F + f];
+  }
+  s_col[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && f < F) gb[f] = ((s_col[0][lane] + s_col[1][lane]) + s_col[2][lane]) + s_col[3][lane];
 }
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -618,6 +652,26 @@ int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
                           stream);
 }
 
+static int act_bias_bwd_launch(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
+                               float slope, float* gP, float* gb, float* partials, void* stream) {
+  const unsigned gx = static_cast<unsigned>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);
+  const unsigned gy = static_cast<unsigned>((F + 63) / 64);
+  const bool v4 = F % 4 == 0 && ld % 4 == 0 && aligned(gY, 16) && aligned(gP, 16) && (!Y || aligned(Y, 16));
+  if (v4)
+    act_bias_bwd_v4_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials);
+  else
+    act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials);
+  SPMI_CHECK_LAUNCH("act_bias_bwd");
+  if (partials) {
+    bias_grad_reduce_kernel<<<gy, kThreads, 0, spmi::as_stream(stream)>>>(partials, static_cast<int>(gx),
+                                                                          static_cast<int>(F), gb);
+    SPMI_CHECK_LAUNCH("bias_grad_reduce");
+  }
+  return SPMI_OK;
+}
+
 int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
                       float slope, float* gP, float* gb, void* stream) {
   SPMI_REQUIRE(M >= 0 && F >= 1 && ld >= F && F < (int64_t{1} << 24), SPMI_ERR_INVALID_ARG,
@@ -627,17 +681,31 @@ int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int
   if (M == 0) return SPMI_OK;
   SPMI_REQUIRE(gY && gP && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
                "spmi_act_bias_bwd: null pointer");
-  const unsigned gx = static_cast<unsigned>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);
-  const unsigned gy = static_cast<unsigned>((F + 63) / 64);
-  const bool v4 = F % 4 == 0 && ld % 4 == 0 && aligned(gY, 16) && aligned(gP, 16) && (!Y || aligned(Y, 16));
-  if (v4)
-    act_bias_bwd_v4_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
-        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
-  else
-    act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
-        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb);
-  SPMI_CHECK_LAUNCH("act_bias_bwd");
-  return SPMI_OK;
+  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, nullptr, stream);
+}
+
+size_t spmi_act_bias_bwd_workspace_bytes(int64_t M, int64_t F) {
+  if (M < 0 || F < 1) return 0;
+  return sizeof(float) * static_cast<size_t>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock) * static_cast<size_t>(F);
+}
+
+int spmi_act_bias_bwd_ordered(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
+                              float slope, float* gP, float* gb, void* ws, size_t ws_bytes, void* stream) {
+  SPMI_REQUIRE(M >= 0 && F >= 1 && ld >= F && F < (int64_t{1} << 24), SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd_ordered: bad sizes");
+  SPMI_REQUIRE(act >= SPMI_ACT_NONE && act <= SPMI_ACT_LEAKY_RELU, SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd_ordered: bad activation code %d", act);
+  SPMI_REQUIRE(gb, SPMI_ERR_INVALID_ARG, "spmi_act_bias_bwd_ordered: null gb");
+  if (M == 0) {
+    SPMI_CHECK_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)F, spmi::as_stream(stream)));
+    return SPMI_OK;
+  }
+  SPMI_REQUIRE(gY && gP && ws && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
+               "spmi_act_bias_bwd_ordered: null pointer");
+  SPMI_REQUIRE(ws_bytes >= spmi_act_bias_bwd_workspace_bytes(M, F), SPMI_ERR_WORKSPACE,
+               "spmi_act_bias_bwd_ordered: workspace %zu < required %zu", ws_bytes,
+               spmi_act_bias_bwd_workspace_bytes(M, F));
+  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, static_cast<float*>(ws), stream);
 }
 
 }  // extern "C"

@@ -82,13 +82,32 @@ class NodeMemory:
         self._memory = table
         self._bounded = None
 
-    def bounded(self) -> bool:
-        """Whether every stored state is below X_BOUND in magnitude (one device round trip
-        after the table was assigned or written through `update_memory`, cached afterwards;
-        the cell kernels keep the property, see X_BOUND)."""
+    def bounded(self, wait: bool = True) -> bool:
+        """Whether every stored state is below X_BOUND in magnitude.  The cell kernels keep the
+        property (see X_BOUND), so the question only comes up after the table was assigned or
+        written through `update_memory`.  `wait=True` answers it with one device round trip.
+        `wait=False` never makes the host wait: the maximum is queued to pinned memory once and
+        the answer is "no" (callers then take the path that assumes nothing) until a later
+        call finds it landed."""
         if self._bounded is None:
             m = self._memory
-            self._bounded = bool(m.numel() == 0 or float(m.abs().max()) < self.X_BOUND)
+            if m.numel() == 0:
+                self._bounded = True
+            elif wait or not m.is_cuda:
+                self._bounded = bool(float(m.abs().max()) < self.X_BOUND)
+                self._bound_check = None
+            else:
+                check = getattr(self, "_bound_check", None)
+                if check is None or check[0] is not m:
+                    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                    host.copy_(m.abs().max().reshape(1), non_blocking=True)
+                    event = torch.cuda.Event()
+                    event.record()
+                    check = self._bound_check = (m, host, event)
+                if not check[2].query():
+                    return False
+                self._bounded = bool(float(check[1][0]) < self.X_BOUND)
+                self._bound_check = None
         return self._bounded
 
     def spare(self) -> torch.Tensor:
@@ -106,6 +125,7 @@ class NodeMemory:
     def update_memory(self, new_memory: torch.Tensor, inx):
         self.memory[:, inx, :] = new_memory.to(self.memory.device)
         self._bounded = None
+        self._bound_check = None   # a check in flight looked at the table before this write
 
     def get_memory(self, inx) -> torch.Tensor:
         return self.memory[:, inx, :]
@@ -249,7 +269,7 @@ class GRU(SequentialDecoder):
         # Every node, nothing tracked: the kernel that keeps the gate weights in LDS.  It
         # cannot update rows in place, so the new state goes to the memory's second table and
         # the two tables trade places afterwards; the returned rows are the new state itself.
-        inner_bounded = mem.bounded()  # layers k > 0 read the state of layer k - 1
+        inner_bounded = mem.bounded(wait=False)  # layers k > 0 read the state of layer k - 1
         whole = (ids is None and x.shape[0] == mem.memory.shape[1]
                  and all(ops.gru_rows_ok(x if k == 0 else mem.memory[k], self._layer_params(k)[1],
                                          *self._layer_params(k)[::2], self._layer_params(k)[3])

@@ -121,20 +121,10 @@ def _plan(indptr: torch.Tensor, n_rows: int, e: int, meta: torch.Tensor, heavy_t
     return heavy_rows, heavy_ptr
 
 
-_meta_pools: Dict = {}
-
-
 def _zeroed_meta(device: torch.device) -> torch.Tensor:
-    """int32[3] (status, n_heavy, n_chunks) of one build, zeroed: a slice of a block of 256 that
-    is zeroed with one fill, so a build launches no fill of its own.  A slice is handed out
-    once; a block lives for as long as one of its slices does."""
-    key = (device.type, device.index)
-    pool = _meta_pools.get(key)
-    if pool is None or pool[1] >= 256:
-        pool = _meta_pools[key] = [torch.zeros(256, 4, dtype=torch.int32, device=device), 0]
-    meta = pool[0][pool[1], :3]
-    pool[1] += 1
-    return meta
+    """int32[3] (status, n_heavy, n_chunks) of one build, zeroed on the current stream without a
+    fill of its own (`_native.zeroed_slot`)."""
+    return nv.zeroed_slot(device, 4)[:3]
 
 
 def _fetch_meta(meta: torch.Tensor):

@@ -32,12 +32,20 @@ def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope:
         g_y = g_y.contiguous()
         y = y.contiguous()
     g_p = torch.empty(m, f, dtype=torch.float32, device=g_y.device)
-    g_b = torch.zeros(f, dtype=torch.float32, device=g_y.device) if want_gb else None
     code = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}[act]
+    lib = nv.lib()
     with torch.cuda.device(g_y.device):
-        nv.check(nv.lib().spmi_act_bias_bwd(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code,
-                                            float(slope), nv.ptr(g_p), nv.ptr(g_b), nv.stream()),
-                 "spmi_act_bias_bwd")
+        if not want_gb:
+            nv.check(lib.spmi_act_bias_bwd(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code, float(slope),
+                                           nv.ptr(g_p), None, nv.stream()), "spmi_act_bias_bwd")
+            return g_p, None
+        # column sums slab by slab, added in slab order: the bias gradient is bit-reproducible
+        g_b = torch.empty(f, dtype=torch.float32, device=g_y.device)
+        ws_bytes = lib.spmi_act_bias_bwd_workspace_bytes(m, f)
+        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=g_y.device)
+        nv.check(lib.spmi_act_bias_bwd_ordered(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code, float(slope),
+                                               nv.ptr(g_p), nv.ptr(g_b), nv.ptr(ws), ws_bytes, nv.stream()),
+                 "spmi_act_bias_bwd_ordered")
     return g_p, g_b
 
 
@@ -808,7 +816,8 @@ class WeightCacheHooks:
     checkpoint) is never multiplied in its old form."""
 
     def train(self, mode: bool = True):
-        invalidate_weight_caches()
+        if bool(mode) != self.training:   # a call that changes nothing keeps the images
+            invalidate_weight_caches()
         return super().train(mode)
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -817,19 +826,10 @@ class WeightCacheHooks:
         invalidate_weight_caches()
 
 
-_amax_pools: dict = {}
-
-
 def _amax_slot(device: torch.device) -> torch.Tensor:
-    """A zeroed int32 device scalar for one domain check: slots come from blocks of 256 that are
-    zeroed in one fill, so a check costs no launch of its own for that."""
-    key = (device.type, device.index)
-    pool = _amax_pools.get(key)
-    if pool is None or pool[1] >= pool[0].numel():
-        pool = _amax_pools[key] = [torch.zeros(256, dtype=torch.int32, device=device), 0]
-    slot = pool[0][pool[1]: pool[1] + 1]
-    pool[1] += 1
-    return slot
+    """A zeroed int32 device scalar for one domain check, valid on the current stream
+    (`_native.zeroed_slot`: no fill launch per check)."""
+    return nv.zeroed_slot(device, 1)
 
 
 class _DomainCheck:
@@ -865,7 +865,9 @@ def weight_planes(w: torch.Tensor, kind: str = "f16x3", transposed: bool = False
     largest |w| the consuming kernel takes.  It is checked whenever planes are (re)built, without
     a host wait: the maximum travels to the host behind the split and is read at a later use of
     the same weight (or when its planes are rebuilt), where an out-of-domain weight raises."""
-    slot_id = (id(w), kind, transposed)
+    # the limit is part of the key: a weight whose planes were checked against a kernel with a
+    # wide domain is split (and checked) again for a kernel with a narrower one
+    slot_id = (id(w), kind, transposed, limit)
     key = (w._version, w.data_ptr(), tuple(w.shape), w.stride(), w.device)
     slot = _plane_cache.get(slot_id)
     if slot is not None and slot[0]() is w:

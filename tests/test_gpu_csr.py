@@ -242,3 +242,28 @@ def test_one_call_build_reports_bad_ids_and_runs_twice(dev):
     a = G.build_csr(dst, src, n, n, want_eid=True, norm_mode=0)
     b = G.build_csr(dst, src, n, n, want_eid=True, norm_mode=0)
     assert torch.equal(a.indices, b.indices) and torch.equal(a.eid, b.eid) and torch.equal(a.norm(0), b.norm(0))
+
+
+def test_builds_on_a_side_stream(dev):
+    """Snapshot builds queued on a stream other than the one an earlier build ran on: the
+    zeroed status / plan words of a build belong to the stream that is current (a block of such
+    words zeroed on one stream is never handed to another), so the range check and the hub-row
+    plan are what they are on the default stream."""
+    n, e = 50_000, 400_000
+    src, dst = orc.powerlaw_snapshot(n, e, t=3, k_dst=6.0)
+    src_t, dst_t = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+    ref = G.build_csr(dst_t, src_t, n, n, want_eid=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    bad = dst_t.clone()
+    bad[7] = n + 5
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            got = G.build_csr(dst_t, src_t, n, n, want_eid=True)
+            assert (got.n_heavy, got.n_chunks) == (ref.n_heavy, ref.n_chunks) and ref.n_heavy > 0
+            assert torch.equal(got.indptr, ref.indptr) and torch.equal(got.indices, ref.indices)
+        with pytest.raises(nv.SpmiError):
+            G.build_csr(bad, src_t, n, n)
+    side.synchronize()
+    again = G.build_csr(dst_t, src_t, n, n)
+    assert (again.n_heavy, again.n_chunks) == (ref.n_heavy, ref.n_chunks)

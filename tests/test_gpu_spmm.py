@@ -145,3 +145,33 @@ def test_activation_and_bias_backward(dev, m, f, pad, act):
     assert torch.equal(g_p, want.contiguous())
     ref_b = want.double().sum(0)
     assert float((g_b.double() - ref_b).abs().max()) <= 1e-5 * max(float(ref_b.abs().max()), 1.0)
+    # the bias gradient is summed slab by slab in a fixed order: the same bits on every launch
+    for _ in range(3):
+        _, again = ops._act_bias_bwd(g_y, y, act, 0.01, True)
+        assert torch.equal(again, g_b)
+    g_p2, none_b = ops._act_bias_bwd(g_y, y, act, 0.01, False)
+    assert none_b is None and torch.equal(g_p2, g_p)
+
+
+def test_bias_gradient_of_a_layer_is_bit_reproducible(dev):
+    """GraphConv forward + backward twice on the same inputs at 300k rows: every gradient,
+    the bias gradient included (fixed-order slab sums, no atomics), comes back bit for bit."""
+    import torch.nn.functional as F
+    from spiral_amd.core.types import GraphConv
+
+    n, e = 300_000, 2_000_000
+    gen = torch.Generator(device=dev).manual_seed(3)
+    src = torch.randint(0, n, (e,), generator=gen, device=dev)
+    dst = (torch.rand(e, generator=gen, device=dev).pow(3) * n).long().clamp_(max=n - 1)
+    x = torch.randn(n, 128, generator=gen, device=dev)
+    torch.manual_seed(0)
+    conv = GraphConv(128, 128, activation=F.leaky_relu, allow_zero_in_degree=True).to(dev)
+    grads = []
+    for _ in range(2):
+        conv.zero_grad()
+        g = G.SnapshotGraph(src, dst, n)
+        xr = x.clone().requires_grad_()
+        (conv(g, xr) ** 2).sum().backward()
+        grads.append((conv.bias.grad.clone(), conv.weight.grad.clone(), xr.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

@@ -58,6 +58,13 @@ def test_static_scratch_matches_workspace_entry_point(dev):
                                   ds.cpu().numpy(), np.abs(bias.cpu().numpy())) + 1e-30
             assert (np.abs(got.cpu().numpy() - ref) / scale).max() <= 1e-5
     assert results[1][1] < results[0][1], "second call must use less of the scratch than the first"
+    # a warmed-up call takes nothing from the device: free memory is the same before and after
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info(dev)
+    nv.check(_call("spmi_gcn_spmm_static", csr, x, ds, bias, got), "spmi_gcn_spmm_static")
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_after == free_before, (free_before, free_after)
 
 
 def test_static_scratch_rejects_plans_beyond_its_size(dev):
