@@ -269,11 +269,15 @@ int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int
                       void* stream);
 /* The same with a bias gradient that is the same bits on every launch: every slab of 512 rows
  * leaves its column sums in the workspace and a second kernel adds the slabs in slab order
- * (gb is written, not accumulated, and needs no zeroing).  Same reference lines. */
+ * (gb is written, not accumulated, and needs no zeroing; gb nullable, then no workspace).
+ * row_scale (nullable, device [M]): gP[r,:] is stored multiplied by row_scale[r] -- the
+ * destination normaliser, so that the backward aggregation that follows needs no per-edge
+ * weight -- while gb sums the unscaled values.  Same reference lines. */
 size_t spmi_act_bias_bwd_workspace_bytes(int64_t M, int64_t F);
 int spmi_act_bias_bwd_ordered(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld,
-                              int act, float slope, float* gP, float* gb /*device [F]*/, void* ws,
-                              size_t ws_bytes, void* stream);
+                              int act, float slope, const float* row_scale /*nullable*/, float* gP,
+                              float* gb /*nullable, device [F]*/, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* ------------------------------------------------------------------------
  * Recurrent cells, sequence length 1, batch = nodes.  Replace the pointwise

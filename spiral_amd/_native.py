@@ -55,8 +55,8 @@ _SIGNATURES = {
                                      c_i32, c_i32, c_i32, c_i32, c_vp]),
     "spmi_act_bias_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp]),
     "spmi_act_bias_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
-    "spmi_act_bias_bwd_ordered": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_sz,
-                                          c_vp]),
+    "spmi_act_bias_bwd_ordered": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                          c_sz, c_vp]),
     "spmi_gather_rows": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "spmi_gru_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_int,
                                   c_vp, c_vp]),

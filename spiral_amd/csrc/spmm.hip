@@ -353,7 +353,8 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
                                                                 int act, float slope,
                                                                 float* __restrict__ gP,
                                                                 float* __restrict__ gb,
-                                                                float* __restrict__ partials) {
+                                                                float* __restrict__ partials,
+                                                                const float* __restrict__ row_scale) {
   __shared__ float s_col[kWavesPerBlock][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_kernel(const float* __r
     for (int64_t r = row0 + wave; r < row1; r += kWavesPerBlock) {
       float g = gY[r * ld + f];
       if (act != SPMI_ACT_NONE) g = (Y[r * ld + f] > 0.0f) ? g : g * neg;
-      gP[r * F + f] = g;
+      gP[r * F + f] = row_scale ? g * row_scale[r] : g;
       col += g;
     }
   }
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
                                                                    int act, float slope,
                                                                    float* __restrict__ gP,
                                                                    float* __restrict__ gb,
-                                                                   float* __restrict__ partials) {
+                                                                   float* __restrict__ partials,
+                                                                   const float* __restrict__ row_scale) {
   __shared__ float4 s_col[16][16];
   const int cg = threadIdx.x & 15;   // column group: columns f .. f + 3
   const int rl = threadIdx.x >> 4;   // 0 .. 15: rows rl, rl + 16, ...
@@ -417,8 +419,12 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
           g[u].z = y[u].z > 0.0f ? g[u].z : g[u].z * neg;
           g[u].w = y[u].w > 0.0f ? g[u].w : g[u].w * neg;
         }
-        *reinterpret_cast<float4*>(gP + (r + 16 * u) * F + f) = g[u];
         col.x += g[u].x; col.y += g[u].y; col.z += g[u].z; col.w += g[u].w;
+        if (row_scale) {
+          const float rs = row_scale[r + 16 * u];
+          g[u].x *= rs; g[u].y *= rs; g[u].z *= rs; g[u].w *= rs;
+        }
+        *reinterpret_cast<float4*>(gP + (r + 16 * u) * F + f) = g[u];
       }
     }
   }
@@ -437,18 +443,18 @@ __global__ __launch_bounds__(kThreads) void act_bias_bwd_v4_kernel(const float* 
   }
 }
 
-// gb[f] = sum over the row slabs of their column sums, in slab order: a wave owns a quarter
-// of the slabs and walks it front to back (lanes = columns), the four wave sums are added in
-// wave order.  No atomics: the same bits on every launch.
-__global__ __launch_bounds__(kThreads) void bias_grad_reduce_kernel(const float* __restrict__ partials,
-                                                                    int n_slabs, int F,
-                                                                    float* __restrict__ gb) {
-  __shared__ float s_col[kWavesPerBlock][64];
+// gb[f] = sum over the row slabs of their column sums, in slab order: each of the sixteen waves
+// owns a sixteenth of the slabs and walks it front to back (lanes = columns, eight loads in
+// flight), the wave sums are added in wave order.  No atomics: the same bits on every launch.
+constexpr int kReduceWaves = 16;
+__global__ __launch_bounds__(64 * kReduceWaves) void bias_grad_reduce_kernel(
+    const float* __restrict__ partials, int n_slabs, int F, float* __restrict__ gb) {
+  __shared__ float s_col[kReduceWaves][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + lane;
-  const int per = (n_slabs + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int s0 = wave * per, s1 = min(s0 + per, n_slabs);
+  const int per = (n_slabs + kReduceWaves - 1) / kReduceWaves;
+  const int s0 = min(wave * per, n_slabs), s1 = min(s0 + per, n_slabs);
   float sum = 0.0f;
   if (f < F) {
     int q = s0;
@@ -463,7 +469,12 @@ __global__ __launch_bounds__(kThreads) void bias_grad_reduce_kernel(const float*
   }
   s_col[wave][lane] = sum;
   __syncthreads();
-  if (wave == 0 && f < F) gb[f] = ((s_col[0][lane] + s_col[1][lane]) + s_col[2][lane]) + s_col[3][lane];
+  if (wave == 0 && f < F) {
+    float total = s_col[0][lane];
+#pragma unroll
+    for (int w = 1; w < kReduceWaves; ++w) total += s_col[w][lane];
+    gb[f] = total;
+  }
 }
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -653,19 +664,20 @@ int spmi_gcn_spmm(const int32_t* indptr, const int32_t* indices, int64_t n_rows,
 }
 
 static int act_bias_bwd_launch(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
-                               float slope, float* gP, float* gb, float* partials, void* stream) {
+                               float slope, float* gP, float* gb, float* partials, const float* row_scale,
+                               void* stream) {
   const unsigned gx = static_cast<unsigned>((M + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);
   const unsigned gy = static_cast<unsigned>((F + 63) / 64);
   const bool v4 = F % 4 == 0 && ld % 4 == 0 && aligned(gY, 16) && aligned(gP, 16) && (!Y || aligned(Y, 16));
   if (v4)
     act_bias_bwd_v4_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
-        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials);
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials, row_scale);
   else
     act_bias_bwd_kernel<<<dim3(gx, gy), kThreads, 0, spmi::as_stream(stream)>>>(
-        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials);
+        gY, Y, M, static_cast<int>(F), ld, act, slope, gP, gb, partials, row_scale);
   SPMI_CHECK_LAUNCH("act_bias_bwd");
   if (partials) {
-    bias_grad_reduce_kernel<<<gy, kThreads, 0, spmi::as_stream(stream)>>>(partials, static_cast<int>(gx),
+    bias_grad_reduce_kernel<<<gy, 64 * kReduceWaves, 0, spmi::as_stream(stream)>>>(partials, static_cast<int>(gx),
                                                                           static_cast<int>(F), gb);
     SPMI_CHECK_LAUNCH("bias_grad_reduce");
   }
@@ -681,7 +693,7 @@ int spmi_act_bias_bwd(const float* gY, const float* Y, int64_t M, int64_t F, int
   if (M == 0) return SPMI_OK;
   SPMI_REQUIRE(gY && gP && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
                "spmi_act_bias_bwd: null pointer");
-  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, nullptr, stream);
+  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, nullptr, nullptr, stream);
 }
 
 size_t spmi_act_bias_bwd_workspace_bytes(int64_t M, int64_t F) {
@@ -690,22 +702,23 @@ size_t spmi_act_bias_bwd_workspace_bytes(int64_t M, int64_t F) {
 }
 
 int spmi_act_bias_bwd_ordered(const float* gY, const float* Y, int64_t M, int64_t F, int64_t ld, int act,
-                              float slope, float* gP, float* gb, void* ws, size_t ws_bytes, void* stream) {
+                              float slope, const float* row_scale, float* gP, float* gb, void* ws,
+                              size_t ws_bytes, void* stream) {
   SPMI_REQUIRE(M >= 0 && F >= 1 && ld >= F && F < (int64_t{1} << 24), SPMI_ERR_INVALID_ARG,
                "spmi_act_bias_bwd_ordered: bad sizes");
   SPMI_REQUIRE(act >= SPMI_ACT_NONE && act <= SPMI_ACT_LEAKY_RELU, SPMI_ERR_INVALID_ARG,
                "spmi_act_bias_bwd_ordered: bad activation code %d", act);
-  SPMI_REQUIRE(gb, SPMI_ERR_INVALID_ARG, "spmi_act_bias_bwd_ordered: null gb");
   if (M == 0) {
-    SPMI_CHECK_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)F, spmi::as_stream(stream)));
+    if (gb) SPMI_CHECK_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)F, spmi::as_stream(stream)));
     return SPMI_OK;
   }
-  SPMI_REQUIRE(gY && gP && ws && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
+  SPMI_REQUIRE(gY && gP && (!gb || ws) && (act == SPMI_ACT_NONE || Y), SPMI_ERR_INVALID_ARG,
                "spmi_act_bias_bwd_ordered: null pointer");
-  SPMI_REQUIRE(ws_bytes >= spmi_act_bias_bwd_workspace_bytes(M, F), SPMI_ERR_WORKSPACE,
+  SPMI_REQUIRE(!gb || ws_bytes >= spmi_act_bias_bwd_workspace_bytes(M, F), SPMI_ERR_WORKSPACE,
                "spmi_act_bias_bwd_ordered: workspace %zu < required %zu", ws_bytes,
                spmi_act_bias_bwd_workspace_bytes(M, F));
-  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, static_cast<float*>(ws), stream);
+  return act_bias_bwd_launch(gY, Y, M, F, ld, act, slope, gP, gb, gb ? static_cast<float*>(ws) : nullptr,
+                             row_scale, stream);
 }
 
 }  // extern "C"

@@ -22,7 +22,8 @@ from torch import nn
 
 from spiral_amd.core.errors import GraphError
 from spiral_amd.graph import SnapshotGraph
-from spiral_amd.ops import (WeightCacheHooks, gcn_aggregate, graphconv_inference, project_rows_inference,
+from spiral_amd.ops import (WeightCacheHooks, gcn_aggregate, graphconv_inference, graphconv_project_first,
+                            project_rows_inference,
                             rows_times_weight)
 
 
@@ -96,6 +97,10 @@ class GraphConv(WeightCacheHooks, nn.Module):
                 and feat.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32):
             # bfloat16 rows against the float32 weight: spmi_gemm_rows_bf16 keeps the weight's value
             rst = graphconv_inference(graph, feat, weight, self._norm, self.bias, code, slope)
+        elif (self._in_feats >= self._out_feats and weight is not None and edge_weight is None and tracked
+              and feat.dtype == torch.float32 and weight.dtype == torch.float32):
+            # the same kernels under autograd (no per-edge weight in either direction)
+            rst = graphconv_project_first(graph, feat, weight, self._norm, self.bias, code, slope)
         if weight is not None and weight.dtype != feat.dtype:
             weight = weight.to(feat.dtype)  # bf16 feature storage on the library path: the projection runs in bf16
         if rst is not None:

@@ -18,15 +18,18 @@ from .graph import _ACT_CODES, aggregate
 
 
 def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope: float,
-                  want_gb: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """gP = gY * act'(Y) and gb = column sums of gP, one pass."""
+                  want_gb: bool, row_scale: Optional[torch.Tensor] = None
+                  ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """gP = gY * act'(Y) and gb = column sums of gP, one pass.  `row_scale` [rows]: gP comes back
+    with its rows multiplied by it (gb sums the unscaled values)."""
     if g_y.dtype != torch.float32:  # bf16 storage: elementwise torch ops, fp32 column sums
         g_p = g_y
         if act == "relu":
             g_p = torch.where(y > 0, g_y, torch.zeros_like(g_y))
         elif act == "leaky_relu":
             g_p = torch.where(y > 0, g_y, g_y * slope)
-        return g_p, (g_p.sum(0, dtype=torch.float32) if want_gb else None)
+        g_b = g_p.sum(0, dtype=torch.float32) if want_gb else None
+        return (g_p if row_scale is None else g_p * row_scale[:, None].to(g_p.dtype)), g_b
     m, f = g_y.shape
     if g_y.stride(1) != 1 or g_y.stride(0) != y.stride(0):
         g_y = g_y.contiguous()
@@ -35,17 +38,16 @@ def _act_bias_bwd(g_y: torch.Tensor, y: torch.Tensor, act: Optional[str], slope:
     code = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}[act]
     lib = nv.lib()
     with torch.cuda.device(g_y.device):
-        if not want_gb:
-            nv.check(lib.spmi_act_bias_bwd(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code, float(slope),
-                                           nv.ptr(g_p), None, nv.stream()), "spmi_act_bias_bwd")
-            return g_p, None
         # column sums slab by slab, added in slab order: the bias gradient is bit-reproducible
-        g_b = torch.empty(f, dtype=torch.float32, device=g_y.device)
-        ws_bytes = lib.spmi_act_bias_bwd_workspace_bytes(m, f)
-        ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=g_y.device)
+        g_b = ws = None
+        ws_bytes = 0
+        if want_gb:
+            g_b = torch.empty(f, dtype=torch.float32, device=g_y.device)
+            ws_bytes = lib.spmi_act_bias_bwd_workspace_bytes(m, f)
+            ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=g_y.device)
         nv.check(lib.spmi_act_bias_bwd_ordered(nv.ptr(g_y), nv.ptr(y), m, f, g_y.stride(0), code, float(slope),
-                                               nv.ptr(g_p), nv.ptr(g_b), nv.ptr(ws), ws_bytes, nv.stream()),
-                 "spmi_act_bias_bwd_ordered")
+                                               nv.ptr(row_scale), nv.ptr(g_p), nv.ptr(g_b), nv.ptr(ws), ws_bytes,
+                                               nv.stream()), "spmi_act_bias_bwd_ordered")
     return g_p, g_b
 
 
@@ -243,6 +245,59 @@ def graphconv_inference(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
     dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
     return aggregate(g.csr(wait=False), rst, None, None, dst_scale,
                      None if bias is None else bias.detach(), act, slope)
+
+
+class _GraphConvProjectFirst(torch.autograd.Function):
+    """A whole GraphConv layer that multiplies first, under autograd, on the kernels of the
+    inference path: Y = act(n_in * A (n_out * (X W)) + b) with the source normaliser in the
+    projection's epilogue, so neither direction gathers or streams a per-edge weight:
+
+      forward   Z = (X W) * n_out (spmi_gemm_rows), Y = act(n_in * (A Z) + b) (one aggregation)
+      backward  P = n_in * (gY * act'(Y)) and gb in one pass (spmi_act_bias_bwd_ordered),
+                gZ = n_out * (A^T P) (one aggregation over the by-source CSR) = d(X W),
+                gW = X^T gZ (spmi_gemm_tn), gX = gZ W^T (spmi_gemm_rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, norm, act, slope):
+        mode = 0 if norm == "both" else 1
+        src_scale = g.norm("out", mode) if norm in ("both", "left") else None
+        dst_scale = g.norm("in", mode) if norm in ("both", "right") else None
+        z = gemm_rows(x.detach(), w.detach().t(), None, None, 0.01, src_scale,
+                      planes=weight_planes(w, "f16x3", True, F16X3_GEMM_ROWS_LIMIT))
+        y = aggregate(g.csr(wait=False), z, None, None, dst_scale, None if bias is None else bias.detach(),
+                      act, slope)
+        ctx.g, ctx.act, ctx.slope, ctx.has_bias = g, act, slope, bias is not None
+        ctx.scales = (src_scale, dst_scale)
+        ctx.save_for_backward(x, w, y if act not in (None, "none") else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, w, y = ctx.saved_tensors
+        src_scale, dst_scale = ctx.scales
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
+            ctx.needs_input_grad[2] and ctx.has_bias
+        g_p, g_b = _act_bias_bwd(g_y, y if y is not None else g_y, ctx.act if y is not None else None,
+                                 ctx.slope, need_b, dst_scale)
+        g_x = g_w = None
+        if need_x or need_w:
+            g_z = aggregate(ctx.g.csr_t(wait=False), g_p, None, None, src_scale, None, None)
+            if need_w:
+                g_w = gemm_tn(x, g_z)
+            if need_x:
+                g_x = _mm_nk(g_z, w)
+        return g_x, g_w, g_b, None, None, None, None
+
+
+def graphconv_project_first(g, feat: torch.Tensor, weight: torch.Tensor, norm: str,
+                            bias: Optional[torch.Tensor], act: Optional[str], slope: float
+                            ) -> Optional[torch.Tensor]:
+    """The tracked form of `graphconv_inference` (float32 rows, shapes of spmi_gemm_rows), or None
+    when the layer is not covered and runs as projection + `gcn_aggregate`."""
+    if norm not in ("both", "left", "right", "none") or feat.dtype != torch.float32 \
+            or weight.dtype != torch.float32 or not _gemm_rows_ok(feat, weight.shape[0], weight.shape[1]):
+        return None
+    return _GraphConvProjectFirst.apply(feat, weight, bias, g, norm, act, slope)
 
 
 def project_rows_inference(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],

@@ -203,3 +203,40 @@ def test_inference_path_against_the_oracle(dev, fi, fo, norm):
     assert calls == [bool(ops._gemm_rows_ok(torch.from_numpy(x).to(dev), fi, fo))]
     assert calls[0] == (fi in (64, 128))
     assert rel(got.cpu(), want) < 1e-5, (fi, fo, norm)
+
+
+@pytest.mark.parametrize("norm", ["both", "right", "left", "none"])
+@pytest.mark.parametrize("fi,fo,act", [(128, 128, "leaky_relu"), (128, 64, "relu"), (64, 32, None)])
+def test_tracked_layer_on_the_inference_kernels(dev, norm, fi, fo, act):
+    """Layers that multiply first, with 6000 rows (spmi_gemm_rows shapes): under autograd they
+    run as one function on the inference kernels -- source normaliser in the projection's
+    epilogue, destination normaliser folded into the activation backward, no per-edge weight in
+    either direction.  Output, loss and every gradient against the torch restatement at 1e-5;
+    hub rows (k_dst = 5) take the chunked path in both directions."""
+    n, e = 6000, 70_000
+    rng = np.random.default_rng(fi + fo)
+    src, dst = orc.powerlaw_snapshot(n, e, t=fo, k_dst=5.0)
+    x = rng.standard_normal((n, fi)).astype(np.float32)
+    w = (rng.standard_normal((fi, fo)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(fo).astype(np.float32)
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    y_ref = orc.graphconv_torch(src, dst, n, xt, wt, bt, norm=norm, act=act)
+    loss_ref = (y_ref ** 2).mean()
+    loss_ref.backward()
+
+    graph = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    conv = _layer(fi, fo, w, b, dev, norm=norm, activation=ACTS[act])
+    xg = torch.tensor(x, device=dev, requires_grad=True)
+    y = conv(graph, xg)
+    assert type(y.grad_fn).__name__.startswith("_GraphConvProjectFirst")
+    loss = (y ** 2).mean()
+    loss.backward()
+    assert rel(y.detach().cpu(), y_ref.detach()) < 1e-5
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-5
+    assert rel(xg.grad.cpu(), xt.grad) < 1e-5
+    assert rel(conv.weight.grad.cpu(), wt.grad) < 1e-5
+    assert rel(conv.bias.grad.cpu(), bt.grad) < 1e-5
+    # parameters only (the first layer of a model: its input needs no gradient)
+    conv.zero_grad()
+    (conv(graph, xg.detach()) ** 2).mean().backward()
+    assert rel(conv.weight.grad.cpu(), wt.grad) < 1e-5 and rel(conv.bias.grad.cpu(), bt.grad) < 1e-5
