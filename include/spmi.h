@@ -94,14 +94,14 @@ int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*de
  * lines as spmi_coo_to_csr (dgl.graph + COOToCSR, spiro/dtdg/types.py:191),
  * spmi_norm_from_indptr (the in_degrees()/clamp/pow of dgl GraphConv.forward,
  * call sites staticGraphEncoder.py:113,116) and spmi_spmm_plan together; the
- * outputs are bit-identical to those three calls.  For 4096 < N <= 2^20 the
- * edges take ONE stable radix pass on the top bits of the row id, after which
- * every bucket of 4096 rows is contiguous and in edge order; the rest is a
- * stable counting sort inside the buckets (segments of 8192 edges, wave-ballot
- * ranking, writes inside a cache-resident window), whose workgroups also write
- * row pointers, normaliser and hub rows: six launches and two passes over the
- * edges instead of sixteen launches and four passes.  Other N run the three
- * calls as they are.
+ * outputs are bit-identical to those three calls.  For 4096 < N <= 2^24 the
+ * edges take stable radix passes on the TOP bits of the row id only (one pass
+ * up to 2^20 rows, two beyond), after which every bucket of 4096 rows is
+ * contiguous and in edge order; the rest is a stable counting sort inside the
+ * buckets (segments of 8192 edges, wave-ballot ranking, writes inside a
+ * cache-resident window), whose workgroups also write row pointers, normaliser
+ * and hub rows: at 1M rows six launches and two passes over the edges instead
+ * of sixteen launches and four passes.  Other N run the three calls as they are.
  *   norm_key  nullable, device [N]: f(row degree), mode as spmi_norm_from_indptr
  *   meta      device int32[3], ZEROED BY THE CALLER: [0] status (non-zero: an
  *             id outside its range, clamped), [1] hub rows, [2] chunks

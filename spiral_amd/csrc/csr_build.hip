@@ -402,15 +402,16 @@ __device__ __forceinline__ void wave_fill_gaps(int32_t* indptr, int64_t start, i
   }
 }
 
+// `shift`: boundaries of (key >> shift), e.g. of buckets of 2^shift rows.
 __global__ __launch_bounds__(kThreads) void csr_finalize_kernel(const uint32_t* __restrict__ keys,
                                                                 int64_t E, int64_t N,
-                                                                int32_t* __restrict__ indptr) {
+                                                                int32_t* __restrict__ indptr, int shift = 0) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   const bool valid = i < E;
   int64_t k = 0, prev = -1;
   if (valid) {
-    k = keys[i];
-    if (i > 0) prev = keys[i - 1];
+    k = keys[i] >> shift;
+    if (i > 0) prev = keys[i - 1] >> shift;
   }
   int64_t gap_start = prev + 1;
   int64_t gap = valid ? (k - prev) : 0;
@@ -598,7 +599,8 @@ constexpr int kSegWaves = kSegThreads / 64;
 constexpr int kSegKeys = 32;                      // edges per thread
 constexpr int kSeg = kSegThreads * kSegKeys;      // edges per segment
 constexpr int kRowsPerThread = kRows / kSegThreads;   // 16 rows = 8 table words = 2 x 16 bytes
-constexpr int kMaxBuckets = 256;
+constexpr int kFastBuckets = 256;    // one pass on the top bits, segment layout worked out per workgroup
+constexpr int kMaxBuckets = 4096;    // several passes on the top bits, segment layout by a kernel
 
 struct SegLoc {
   int bucket, seg_in_bucket;
@@ -621,19 +623,43 @@ __device__ __forceinline__ uint32_t seg_block_scan(uint32_t v, uint32_t* s_wave,
   return base + incl - v;
 }
 
+// Where the buckets and their segments are.  Up to 256 buckets (one pass on the top bits) every
+// workgroup works it out from that pass's digit totals; beyond that (several passes on the top
+// bits) the bucket starts come from the sorted keys and a small kernel lays the segments out.
+struct SegMap {
+  const uint32_t* totals;     // <= 256 buckets: edges per bucket
+  const int32_t* bstart;      // otherwise: first edge of every bucket, [n_buckets + 1]
+  const uint32_t* seg_base;   //            first segment of every bucket, [n_buckets + 1]
+  const uint2* desc;          //            (bucket, segment inside it) of every segment
+  int n_buckets, grid;
+};
+
 // Which segment of which bucket this workgroup owns.  Every bucket has at least one segment
 // (an empty bucket still has row pointers to write).  Workgroup numbers are dealt so that
 // consecutive segments run on one XCD (workgroups go round the 8 XCDs).  False: no such segment.
-__device__ __forceinline__ bool locate_segment(const uint32_t* __restrict__ totals, int n_buckets, int grid,
-                                               SegLoc* s_loc, uint32_t* s_wave) {
-  const int seg = static_cast<int>(blockIdx.x & 7) * (grid >> 3) + static_cast<int>(blockIdx.x >> 3);
+__device__ __forceinline__ bool locate_segment(const SegMap& m, SegLoc* s_loc, uint32_t* s_wave) {
+  const int seg = static_cast<int>(blockIdx.x & 7) * (m.grid >> 3) + static_cast<int>(blockIdx.x >> 3);
   const int tid = threadIdx.x;
-  const uint32_t cnt = tid < n_buckets ? totals[tid] : 0u;
-  const uint32_t segs = tid < n_buckets ? max(1u, (cnt + kSeg - 1) / kSeg) : 0u;
+  if (m.desc) {   // uniform
+    if (static_cast<uint32_t>(seg) >= m.seg_base[m.n_buckets]) return false;
+    if (tid == 0) {
+      const uint2 d = m.desc[seg];
+      s_loc->bucket = static_cast<int>(d.x);
+      s_loc->seg_in_bucket = static_cast<int>(d.y);
+      s_loc->seg_base = m.seg_base[d.x];
+      s_loc->n_seg = m.seg_base[d.x + 1] - m.seg_base[d.x];
+      s_loc->bstart = static_cast<uint32_t>(m.bstart[d.x]);
+      s_loc->bcount = static_cast<uint32_t>(m.bstart[d.x + 1] - m.bstart[d.x]);
+    }
+    __syncthreads();
+    return true;
+  }
+  const uint32_t cnt = tid < m.n_buckets ? m.totals[tid] : 0u;
+  const uint32_t segs = tid < m.n_buckets ? max(1u, (cnt + kSeg - 1) / kSeg) : 0u;
   uint32_t total_cnt, total_segs;
   const uint32_t bstart = seg_block_scan(cnt, s_wave, &total_cnt);
   const uint32_t sbase = seg_block_scan(segs, s_wave, &total_segs);
-  if (tid < n_buckets && static_cast<uint32_t>(seg) >= sbase && static_cast<uint32_t>(seg) < sbase + segs) {
+  if (tid < m.n_buckets && static_cast<uint32_t>(seg) >= sbase && static_cast<uint32_t>(seg) < sbase + segs) {
     s_loc->bucket = tid;
     s_loc->seg_in_bucket = seg - static_cast<int>(sbase);
     s_loc->n_seg = segs;
@@ -645,17 +671,53 @@ __device__ __forceinline__ bool locate_segment(const uint32_t* __restrict__ tota
   return static_cast<uint32_t>(seg) < total_segs;
 }
 
+// More than 256 buckets: first segment of every bucket (a scan of ceil(count / 8192), at least
+// one each) and the (bucket, segment) pair of every segment.  One workgroup; buckets are few.
+__global__ __launch_bounds__(1024) void seg_layout_kernel(const int32_t* __restrict__ bstart, int n_buckets,
+                                                          uint32_t* __restrict__ seg_base,
+                                                          uint2* __restrict__ desc) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < n_buckets; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    uint32_t segs = 0;
+    if (b < n_buckets) {
+      const uint32_t cnt = static_cast<uint32_t>(bstart[b + 1] - bstart[b]);
+      segs = max(1u, (cnt + kSeg - 1) / kSeg);
+    }
+    const uint32_t incl = wave_inclusive_scan(segs);
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t c = s_wave[w];
+      if (w < static_cast<int>(threadIdx.x >> 6)) base += c;
+      sum += c;
+    }
+    const uint32_t first = s_carry + base + incl - segs;
+    if (b < n_buckets) {
+      seg_base[b] = first;
+      for (uint32_t j = 0; j < segs; ++j) desc[first + j] = make_uint2(static_cast<uint32_t>(b), j);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += sum;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg_base[n_buckets] = s_carry;
+}
+
 __global__ __launch_bounds__(kSegThreads) void seg_count_kernel(const uint32_t* __restrict__ keys,
-                                                                const uint32_t* __restrict__ totals,
-                                                                int n_buckets, int grid,
-                                                                uint32_t* __restrict__ table) {
+                                                                SegMap map, uint32_t* __restrict__ table) {
   __shared__ uint32_t s_hist[kRowWords];
   __shared__ uint32_t s_wave[kSegWaves];
   __shared__ SegLoc s_loc;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < kRowWords / kSegThreads; ++i) s_hist[i * kSegThreads + tid] = 0;
-  if (!locate_segment(totals, n_buckets, grid, &s_loc, s_wave)) return;
+  if (!locate_segment(map, &s_loc, s_wave)) return;
   const SegLoc L = s_loc;
   const uint32_t lo = L.bstart + static_cast<uint32_t>(L.seg_in_bucket) * kSeg;
   const uint32_t hi = min(lo + kSeg, L.bstart + L.bcount);
@@ -682,8 +744,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_count_kernel(const uint32_t* 
 template <int NVAL>
 __global__ __launch_bounds__(kSegThreads) void seg_place_kernel(
     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ v0_in, const uint32_t* __restrict__ v1_in,
-    const uint32_t* __restrict__ totals, int n_buckets, int grid, const uint32_t* __restrict__ table,
-    int64_t E, int64_t N, int32_t* __restrict__ indptr, uint32_t* __restrict__ v0_out,
+    SegMap map, const uint32_t* __restrict__ table, int64_t E, int64_t N, int32_t* __restrict__ indptr, uint32_t* __restrict__ v0_out,
     uint32_t* __restrict__ v1_out, float* __restrict__ norm, int mode, int32_t heavy_thresh,
     int32_t* __restrict__ heavy_rows, int64_t capacity, int32_t* counts) {
   __shared__ __align__(16) uint16_t s_cnt[kSegWaves][kRows];
@@ -700,7 +761,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_place_kernel(
     for (int i = 0; i < static_cast<int>(sizeof(s_cnt) / 16) / kSegThreads; ++i)
       z[i * kSegThreads + tid] = make_uint4(0, 0, 0, 0);
   }
-  if (!locate_segment(totals, n_buckets, grid, &s_loc, s_wave)) return;
+  if (!locate_segment(map, &s_loc, s_wave)) return;
+  const int n_buckets = map.n_buckets;
   const SegLoc L = s_loc;
   const uint32_t lo = L.bstart + static_cast<uint32_t>(L.seg_in_bucket) * kSeg;
   const uint32_t hi = min(lo + kSeg, L.bstart + L.bcount);
@@ -977,8 +1039,8 @@ int spmi_coo_to_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t
   return SPMI_OK;
 }
 
-// True when the one-pass + bucket-stage build applies: more than one bucket of 4096 rows and
-// at most 256 of them (the pass on the top bits has digits of at most 8 bits).
+// True when the bucket-stage build applies: more than one bucket of 4096 rows and at most 4096
+// of them (N <= 2^24).  Up to 256 buckets the top bits take one radix pass, beyond that two.
 static bool bucket_build_applies(int64_t E, int64_t N) {
   return E > 0 && N > kRows && N <= (static_cast<int64_t>(kMaxBuckets) << kLow);
 }
@@ -988,6 +1050,11 @@ static int bucket_build_grid(int64_t E, int n_buckets) {
   return static_cast<int>((segs + 7) / 8 * 8);
 }
 
+static size_t bucket_layout_bytes(int64_t E, int n_buckets) {
+  return spmi::align_up(sizeof(int32_t) * (size_t)(n_buckets + 1), 256) * 2 +
+         spmi::align_up(sizeof(uint2) * (size_t)bucket_build_grid(E, n_buckets), 256);
+}
+
 size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N) {
   if (E < 0 || N < 1) return 0;
   size_t bytes = spmi_coo_to_csr_workspace_bytes(E, N);
@@ -995,7 +1062,7 @@ size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N) {
     const int n_buckets = static_cast<int>((N + kRows - 1) >> kLow);
     const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
     const size_t table = sizeof(uint32_t) * kRowWords * (size_t)bucket_build_grid(E, n_buckets);
-    bytes = std::max(bytes, 3 * e4 + sort_scratch_bytes(E, N) + table);
+    bytes = std::max(bytes, 4 * e4 + sort_scratch_bytes(E, N) + bucket_layout_bytes(E, n_buckets) + table);
   }
   return bytes;
 }
@@ -1015,7 +1082,7 @@ int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64
                spmi_snapshot_csr_workspace_bytes(E, N));
   hipStream_t st = spmi::as_stream(stream);
   if (!bucket_build_applies(E, N)) {
-    // a single bucket, or more than 256 of them: the three-pass sort and its separate kernels
+    // a single bucket, or more than 4096 of them: the radix sort on every bit and its separate kernels
     if (int rc = spmi_coo_to_csr(key, other, E, N, N_other, indptr, indices, eid, ws, ws_bytes, meta, stream))
       return rc;
     if (norm_key)
@@ -1028,45 +1095,92 @@ int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64
   SPMI_REQUIRE(key && other && indices && ws, SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: null pointer argument");
   int bits = 1;
   while ((int64_t{1} << bits) < N) ++bits;
-  const int top = bits - kLow;                      // 1..8
+  const int top = bits - kLow;                      // 1..12
+  const int passes = top <= 8 ? 1 : 2;
+  const int pass_bits[2] = {passes == 1 ? top : top / 2, top - top / 2};
   const int n_buckets = static_cast<int>((N + kRows - 1) >> kLow);
   const int n_tiles = static_cast<int>((E + kTile - 1) / kTile);
   const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
   char* p = static_cast<char*>(ws);
-  uint32_t* keys_b = reinterpret_cast<uint32_t*>(p);
-  uint32_t* v0_b = reinterpret_cast<uint32_t*>(p + e4);
-  uint32_t* v1_b = reinterpret_cast<uint32_t*>(p + 2 * e4);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(p + 3 * e4);
+  // the last pass must leave its result in workspace buffers (the bucket stage writes `indices`
+  // and `eid`); an earlier pass may use those two arrays as its output
+  uint32_t* keys_ab[2] = {reinterpret_cast<uint32_t*>(p), reinterpret_cast<uint32_t*>(p + e4)};
+  uint32_t* v0_ab[2] = {reinterpret_cast<uint32_t*>(p + 2 * e4), reinterpret_cast<uint32_t*>(indices)};
+  uint32_t* v1_ab[2] = {reinterpret_cast<uint32_t*>(p + 3 * e4), reinterpret_cast<uint32_t*>(eid)};
+  char* q = p + 4 * e4;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(q);
   const size_t hist_bytes = spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)n_tiles, 256);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(p + 3 * e4 + hist_bytes);
-  uint32_t* table = reinterpret_cast<uint32_t*>(p + 3 * e4 + sort_scratch_bytes(E, N));
+  uint32_t* totals = reinterpret_cast<uint32_t*>(q + hist_bytes);
+  q += sort_scratch_bytes(E, N);
+  const size_t nb_bytes = spmi::align_up(sizeof(int32_t) * (size_t)(n_buckets + 1), 256);
+  int32_t* bstart = reinterpret_cast<int32_t*>(q);
+  uint32_t* seg_base = reinterpret_cast<uint32_t*>(q + nb_bytes);
+  uint2* desc = reinterpret_cast<uint2*>(q + 2 * nb_bytes);
+  uint32_t* table = reinterpret_cast<uint32_t*>(q + bucket_layout_bytes(E, n_buckets));
   int32_t* status = meta;
   const dim3 grid(n_tiles), block(kThreads);
-  radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(key, E, (uint32_t)N, kLow, top, hist, n_tiles, status);
-  SPMI_CHECK_LAUNCH("radix_hist(bucket)");
-  radix_scan_kernel<<<dim3(1 << top), block, 0, st>>>(hist, n_tiles, totals);
-  SPMI_CHECK_LAUNCH("radix_scan(bucket)");
-  if (eid) {
-    radix_scatter_kernel<int64_t, true, 2><<<grid, block, 0, st>>>(
-        key, other, nullptr, nullptr, keys_b, v0_b, v1_b, E, (uint32_t)N, (uint32_t)N_other, kLow, top,
-        hist, totals, n_tiles, status);
-  } else {
-    radix_scatter_kernel<int64_t, true, 1><<<grid, block, 0, st>>>(
-        key, other, nullptr, nullptr, keys_b, v0_b, nullptr, E, (uint32_t)N, (uint32_t)N_other, kLow, top,
-        hist, totals, n_tiles, status);
+  int shift = kLow;
+  for (int ps = 0; ps < passes; ++ps) {
+    const int out = (passes - 1 - ps) & 1, in = out ^ 1;
+    const int pb = pass_bits[ps];
+    if (ps == 0) {
+      radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(key, E, (uint32_t)N, shift, pb, hist, n_tiles, status);
+    } else {
+      radix_hist_kernel<uint32_t><<<grid, block, 0, st>>>(keys_ab[in], E, (uint32_t)N, shift, pb, hist, n_tiles,
+                                                          status);
+    }
+    SPMI_CHECK_LAUNCH("radix_hist(bucket)");
+    radix_scan_kernel<<<dim3(1 << pb), block, 0, st>>>(hist, n_tiles, totals);
+    SPMI_CHECK_LAUNCH("radix_scan(bucket)");
+    if (ps == 0 && eid) {
+      radix_scatter_kernel<int64_t, true, 2><<<grid, block, 0, st>>>(
+          key, other, nullptr, nullptr, keys_ab[out], v0_ab[out], v1_ab[out], E, (uint32_t)N, (uint32_t)N_other,
+          shift, pb, hist, totals, n_tiles, status);
+    } else if (ps == 0) {
+      radix_scatter_kernel<int64_t, true, 1><<<grid, block, 0, st>>>(
+          key, other, nullptr, nullptr, keys_ab[out], v0_ab[out], nullptr, E, (uint32_t)N, (uint32_t)N_other,
+          shift, pb, hist, totals, n_tiles, status);
+    } else if (eid) {
+      radix_scatter_kernel<uint32_t, false, 2><<<grid, block, 0, st>>>(
+          keys_ab[in], nullptr, v0_ab[in], v1_ab[in], keys_ab[out], v0_ab[out], v1_ab[out], E, (uint32_t)N,
+          (uint32_t)N_other, shift, pb, hist, totals, n_tiles, status);
+    } else {
+      radix_scatter_kernel<uint32_t, false, 1><<<grid, block, 0, st>>>(
+          keys_ab[in], nullptr, v0_ab[in], nullptr, keys_ab[out], v0_ab[out], nullptr, E, (uint32_t)N,
+          (uint32_t)N_other, shift, pb, hist, totals, n_tiles, status);
+    }
+    SPMI_CHECK_LAUNCH("radix_scatter(bucket)");
+    shift += pb;
   }
-  SPMI_CHECK_LAUNCH("radix_scatter(bucket)");
+  const uint32_t* keys_b = keys_ab[0];
+  const uint32_t* v0_b = v0_ab[0];
+  const uint32_t* v1_b = v1_ab[0];
   const int sgrid = bucket_build_grid(E, n_buckets);
-  seg_count_kernel<<<sgrid, kSegThreads, 0, st>>>(keys_b, totals, n_buckets, sgrid, table);
+  SegMap map{};
+  map.n_buckets = n_buckets;
+  map.grid = sgrid;
+  if (n_buckets <= kFastBuckets && passes == 1) {
+    map.totals = totals;
+  } else {
+    csr_finalize_kernel<<<static_cast<int>((E + kThreads - 1) / kThreads), kThreads, 0, st>>>(
+        keys_b, E, n_buckets, bstart, kLow);
+    SPMI_CHECK_LAUNCH("bucket_bounds");
+    seg_layout_kernel<<<1, 1024, 0, st>>>(bstart, n_buckets, seg_base, desc);
+    SPMI_CHECK_LAUNCH("seg_layout");
+    map.bstart = bstart;
+    map.seg_base = seg_base;
+    map.desc = desc;
+  }
+  seg_count_kernel<<<sgrid, kSegThreads, 0, st>>>(keys_b, map, table);
   SPMI_CHECK_LAUNCH("seg_count");
   if (eid) {
     seg_place_kernel<2><<<sgrid, kSegThreads, 0, st>>>(
-        keys_b, v0_b, v1_b, totals, n_buckets, sgrid, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices),
+        keys_b, v0_b, v1_b, map, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices),
         reinterpret_cast<uint32_t*>(eid), norm_key, norm_mode, heavy_thresh, heavy_rows, capacity - 1, meta + 1);
   } else {
     seg_place_kernel<1><<<sgrid, kSegThreads, 0, st>>>(
-        keys_b, v0_b, nullptr, totals, n_buckets, sgrid, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices),
-        nullptr, norm_key, norm_mode, heavy_thresh, heavy_rows, capacity - 1, meta + 1);
+        keys_b, v0_b, nullptr, map, table, E, N, indptr, reinterpret_cast<uint32_t*>(indices), nullptr, norm_key,
+        norm_mode, heavy_thresh, heavy_rows, capacity - 1, meta + 1);
   }
   SPMI_CHECK_LAUNCH("seg_place");
   plan_finish_kernel<<<1, kPlanThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr, capacity - 1,

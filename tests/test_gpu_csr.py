@@ -196,10 +196,15 @@ def _old_three_calls(key, other, n, n_other, want_eid, mode, dev):
 
 @pytest.mark.parametrize("n,e,k_dst,mode", [(4097, 30_000, 3.0, 0), (5000, 8192, 1.0, 1), (70_000, 400_001, 3.0, 0),
                                             (300_000, 2_000_000, 6.0, 0), (1 << 20, 3_000_000, 3.0, 1),
-                                            (1_000_000, 10_000_000, 3.0, 0), (200_000, 1_000_000, 40.0, 0)])
+                                            (1_000_000, 10_000_000, 3.0, 0), (200_000, 1_000_000, 40.0, 0),
+                                            # more than 256 buckets: two passes on the top bits, segment
+                                            # layout by its own kernel
+                                            ((1 << 20) + 1, 3_000_000, 3.0, 0), (3_000_000, 5_000_000, 6.0, 1),
+                                            (10_000_000, 20_000_000, 3.0, 0), (1 << 24, 4_000_000, 3.0, 0),
+                                            ((1 << 24) + 1, 4_000_000, 3.0, 0)])
 def test_one_call_build_equals_the_three_calls(dev, n, e, k_dst, mode):
-    """spmi_snapshot_csr on its bucket path (4096 < N <= 2^20: one radix pass + the sort inside
-    buckets of 4096 rows) against the three-pass sort, the normaliser kernel and the plan
+    """spmi_snapshot_csr on its bucket path (4096 < N <= 2^24: one or two radix passes on the top
+    bits + the sort inside buckets of 4096 rows) against the radix sort on every bit, the normaliser kernel and the plan
     kernels: row pointers, column ids, edge ids and the normaliser bit for bit, the same set of
     hub rows with the same chunk counts (their order is free).  k_dst = 40 puts most edges on a
     handful of rows (buckets of many segments, empty buckets beside them)."""
