@@ -450,8 +450,9 @@ constexpr int kCountLow = 12;
 constexpr int kCountThreads = 1024;
 
 __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ totals, int64_t N,
-    int64_t* __restrict__ deg, float* __restrict__ norm, int mode) {
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ totals,
+    const int32_t* __restrict__ bstart, int64_t N, int64_t* __restrict__ deg, float* __restrict__ norm,
+    int mode) {
   __shared__ uint32_t s_hist[1 << kCountLow];
   __shared__ uint32_t s_start;
   const int b = blockIdx.x;
@@ -459,9 +460,12 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
   for (int j = tid; j < (1 << kCountLow); j += kCountThreads) s_hist[j] = 0;
   if (tid == 0) s_start = 0;
   __syncthreads();
-  if (tid < b) atomicAdd(&s_start, totals[tid]);  // at most 256 buckets: b <= 255 < blockDim
+  // where the bucket's keys are: from the bucket starts when there are more than 256 buckets,
+  // else from the digit totals of the one pass that grouped them
+  if (!bstart && tid < b) atomicAdd(&s_start, totals[tid]);  // b <= 255 < blockDim
   __syncthreads();
-  const uint32_t start = s_start, count = totals[b];
+  const uint32_t start = bstart ? static_cast<uint32_t>(bstart[b]) : s_start;
+  const uint32_t count = bstart ? static_cast<uint32_t>(bstart[b + 1] - bstart[b]) : totals[b];
   for (uint32_t i = tid; i < count; i += kCountThreads)
     atomicAdd(&s_hist[keys[start + i] & ((1u << kCountLow) - 1u)], 1u);
   __syncthreads();
@@ -990,6 +994,58 @@ size_t sort_scratch_bytes(int64_t E, int64_t N) {
          spmi::align_up(sizeof(uint32_t) * kMaxDigits, 256);
 }
 
+// Counts per node by grouping the ids into buckets of 4096 nodes and counting every bucket in
+// LDS (N <= 2^24).  Up to 256 buckets: one grouping pass, in any order.  Up to 4096: two passes
+// on the bucket number, the first in any order, the second stable (it must keep the first one's
+// grouping), then the bucket starts from the sorted keys.
+template <typename KeyT>
+static int degree_by_buckets(const KeyT* ids, int64_t E, int64_t N, int64_t* deg, float* norm, int mode,
+                             uint32_t* keys_a, uint32_t* keys_b, int32_t* bstart, uint32_t* hist,
+                             uint32_t* totals, int32_t* status, hipStream_t st) {
+  const int n_tiles = static_cast<int>((E + kTile - 1) / kTile);
+  const int n_buckets = static_cast<int>((N + (1 << kCountLow) - 1) >> kCountLow);
+  int bits = 1;
+  while ((1 << bits) < n_buckets) ++bits;
+  const dim3 grid(n_tiles), block(kThreads);
+  if (bits <= 8) {
+    radix_hist_kernel<KeyT><<<grid, block, 0, st>>>(ids, E, (uint32_t)N, kCountLow, bits, hist, n_tiles, status);
+    SPMI_CHECK_LAUNCH("radix_hist(degree)");
+    radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(hist, n_tiles, totals);
+    SPMI_CHECK_LAUNCH("radix_scan(degree)");
+    bucket_scatter_kernel<KeyT><<<grid, block, 0, st>>>(ids, keys_a, E, (uint32_t)N, kCountLow, bits, hist,
+                                                        totals, n_tiles, status);
+    SPMI_CHECK_LAUNCH("bucket_scatter(degree)");
+    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(keys_a, totals, nullptr, N, deg, norm, mode);
+    SPMI_CHECK_LAUNCH("bucket_count");
+    return SPMI_OK;
+  }
+  const int lo_bits = bits / 2, hi_bits = bits - lo_bits;
+  radix_hist_kernel<KeyT><<<grid, block, 0, st>>>(ids, E, (uint32_t)N, kCountLow, lo_bits, hist, n_tiles, status);
+  SPMI_CHECK_LAUNCH("radix_hist(degree)");
+  radix_scan_kernel<<<dim3(1 << lo_bits), block, 0, st>>>(hist, n_tiles, totals);
+  SPMI_CHECK_LAUNCH("radix_scan(degree)");
+  bucket_scatter_kernel<KeyT><<<grid, block, 0, st>>>(ids, keys_b, E, (uint32_t)N, kCountLow, lo_bits, hist,
+                                                      totals, n_tiles, status);
+  SPMI_CHECK_LAUNCH("bucket_scatter(degree)");
+  radix_hist_kernel<uint32_t><<<grid, block, 0, st>>>(keys_b, E, (uint32_t)N, kCountLow + lo_bits, hi_bits, hist,
+                                                      n_tiles, nullptr);
+  SPMI_CHECK_LAUNCH("radix_hist(degree)");
+  radix_scan_kernel<<<dim3(1 << hi_bits), block, 0, st>>>(hist, n_tiles, totals);
+  SPMI_CHECK_LAUNCH("radix_scan(degree)");
+  radix_scatter_kernel<uint32_t, false, 0><<<grid, block, 0, st>>>(
+      keys_b, nullptr, nullptr, nullptr, keys_a, nullptr, nullptr, E, (uint32_t)N, 1u, kCountLow + lo_bits,
+      hi_bits, hist, totals, n_tiles, nullptr);
+  SPMI_CHECK_LAUNCH("radix_scatter(degree)");
+  csr_finalize_kernel<<<static_cast<int>((E + kThreads - 1) / kThreads), kThreads, 0, st>>>(
+      keys_a, E, n_buckets, bstart, kCountLow);
+  SPMI_CHECK_LAUNCH("bucket_bounds(degree)");
+  bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(keys_a, nullptr, bstart, N, deg, norm, mode);
+  SPMI_CHECK_LAUNCH("bucket_count");
+  return SPMI_OK;
+}
+
+constexpr int64_t kBucketDegreeMaxN = int64_t{1} << (kCountLow + 12);   // 4096 buckets of 4096 nodes
+
 }  // namespace
 
 extern "C" {
@@ -1220,24 +1276,9 @@ int spmi_degree(const int64_t* ids, int64_t E, int64_t N, int64_t* deg, void* ws
   b.hist = reinterpret_cast<uint32_t*>(p + 2 * e4 + np);
   b.totals = reinterpret_cast<uint32_t*>(
       p + 2 * e4 + np + spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)sh.n_tiles, 256));
-  if (N <= (int64_t{1} << (kCountLow + 8))) {
-    // up to 256 buckets of 4096 nodes: one scatter pass on the bucket number, then LDS counts
-    const int n_buckets = static_cast<int>((N + (1 << kCountLow) - 1) >> kCountLow);
-    int bits = 1;
-    while ((1 << bits) < n_buckets) ++bits;
-    const dim3 grid(sh.n_tiles), block(kThreads);
-    radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(ids, E, (uint32_t)N, kCountLow, bits, b.hist,
-                                                       sh.n_tiles, status);
-    SPMI_CHECK_LAUNCH("radix_hist(degree)");
-    radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
-    SPMI_CHECK_LAUNCH("radix_scan(degree)");
-    bucket_scatter_kernel<int64_t><<<grid, block, 0, st>>>(ids, b.keys[0], E, (uint32_t)N, kCountLow, bits,
-                                                           b.hist, b.totals, sh.n_tiles, status);
-    SPMI_CHECK_LAUNCH("bucket_scatter(degree)");
-    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, nullptr, 0);
-    SPMI_CHECK_LAUNCH("bucket_count");
-    return SPMI_OK;
-  }
+  if (N <= kBucketDegreeMaxN)
+    return degree_by_buckets<int64_t>(ids, E, N, deg, nullptr, 0, b.keys[0], b.keys[1], indptr, b.hist, b.totals,
+                                      status, st);
   if (int rc = run_sort<0>(ids, nullptr, E, N, 1, sh, b, status, st)) return rc;
   const int grid = static_cast<int>((E + kThreads - 1) / kThreads);
   csr_finalize_kernel<<<grid, kThreads, 0, st>>>(b.keys[0], E, N, indptr);
@@ -1272,22 +1313,9 @@ int spmi_norm_from_ids32(const int32_t* ids, int64_t E, int64_t N, int mode, flo
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(ids);
   const dim3 grid(sh.n_tiles), block(kThreads);
   int32_t* no_status = nullptr;  // 32-bit keys are never range-checked (checked_key passes them through)
-  if (E > 0 && N <= (int64_t{1} << (kCountLow + 8))) {
-    const int n_buckets = static_cast<int>((N + (1 << kCountLow) - 1) >> kCountLow);
-    int bits = 1;
-    while ((1 << bits) < n_buckets) ++bits;
-    radix_hist_kernel<uint32_t><<<grid, block, 0, st>>>(keys, E, (uint32_t)N, kCountLow, bits, b.hist,
-                                                        sh.n_tiles, no_status);
-    SPMI_CHECK_LAUNCH("radix_hist(ids32)");
-    radix_scan_kernel<<<dim3(1 << bits), block, 0, st>>>(b.hist, sh.n_tiles, b.totals);
-    SPMI_CHECK_LAUNCH("radix_scan(ids32)");
-    bucket_scatter_kernel<uint32_t><<<grid, block, 0, st>>>(keys, b.keys[0], E, (uint32_t)N, kCountLow, bits,
-                                                            b.hist, b.totals, sh.n_tiles, no_status);
-    SPMI_CHECK_LAUNCH("bucket_scatter(ids32)");
-    bucket_count_kernel<<<n_buckets, kCountThreads, 0, st>>>(b.keys[0], b.totals, N, deg, norm, mode);
-    SPMI_CHECK_LAUNCH("bucket_count(ids32)");
-    return SPMI_OK;
-  }
+  if (E > 0 && N <= kBucketDegreeMaxN)
+    return degree_by_buckets<uint32_t>(keys, E, N, deg, norm, mode, b.keys[0], b.keys[1], indptr, b.hist,
+                                       b.totals, no_status, st);
   if (E == 0) {
     SPMI_CHECK_HIP(hipMemsetAsync(indptr, 0, sizeof(int32_t) * (size_t)(N + 1), st));
   } else {

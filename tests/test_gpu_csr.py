@@ -74,16 +74,23 @@ def test_out_of_range_id_is_reported(dev):
 
 
 @pytest.mark.parametrize("n,e", [(1, 7), (4096, 50_000), (4097, 50_000), (300_000, 2_000_000), (1 << 20, 3_000_000),
-                                 ((1 << 20) + 1, 3_000_000)])
+                                 ((1 << 20) + 1, 3_000_000), (7_000_000, 12_000_000), (1 << 24, 3_000_000),
+                                 ((1 << 24) + 1, 3_000_000)])
 def test_degree_bucket_and_sort_paths(dev, n, e):
-    """Up to 2^20 nodes degrees come from one bucket pass + LDS counters, above from the
-    keys-only sort; both must equal a bincount, hubs included."""
+    """Up to 2^20 nodes degrees come from one grouping pass into buckets of 4096 nodes + LDS
+    counters, up to 2^24 from two such passes (the second stable) and the bucket starts, above
+    from the keys-only sort; all must equal a bincount, hubs included; the same for the
+    normaliser counted from a 32-bit id column."""
     rng = np.random.default_rng(n + e)
     ids = rng.integers(0, n, e, dtype=np.int64)
     ids[: e // 3] = ids[0]                      # a hub holding a third of all entries
     ids[e // 3: e // 2] = n - 1                 # and the last node
+    want = np.bincount(ids, minlength=n)
     got = G.degree(torch.from_numpy(ids).to(dev), n).cpu().numpy()
-    assert np.array_equal(got, np.bincount(ids, minlength=n))
+    assert np.array_equal(got, want)
+    norm = G.norm_from_ids32(torch.from_numpy(ids.astype(np.int32)).to(dev), n, 0)
+    ref = 1.0 / torch.from_numpy(want).to(dev).to(torch.float32).clamp(min=1).sqrt()
+    assert torch.equal(norm, ref)
 
 
 def test_deferred_build_reports_at_first_use(dev):
