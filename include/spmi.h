@@ -103,15 +103,24 @@ int spmi_coo_to_csr(const int64_t* key /*device [E]*/, const int64_t* other /*de
  * and hub rows: at 1M rows six launches and two passes over the edges instead
  * of sixteen launches and four passes.  Other N run the three calls as they are.
  *   norm_key  nullable, device [N]: f(row degree), mode as spmi_norm_from_indptr
+ *   norm_other nullable, device [N_other]: the same f of the number of edges whose other end
+ *             is the node (the source normaliser beside a by-destination CSR): the first pass
+ *             reads both id arrays anyway, so the grouping of the other endpoints into buckets
+ *             of 4096 nodes rides on it (one more histogram per tile, one unordered scatter
+ *             from registers) and a counting kernel follows.  Only where
+ *             spmi_snapshot_csr_norm_other_supported(E, N, N_other) (N and N_other <= 2^20);
+ *             elsewhere pass NULL and call spmi_norm_from_ids32 on `indices`
  *   meta      device int32[3], ZEROED BY THE CALLER: [0] status (non-zero: an
  *             id outside its range, clamped), [1] hub rows, [2] chunks
  *   heavy_*   as spmi_spmm_plan; the order of heavy_rows is not specified
  * ---------------------------------------------------------------------- */
 size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N);
+int spmi_snapshot_csr_norm_other_supported(int64_t E, int64_t N, int64_t N_other);
 int spmi_snapshot_csr(const int64_t* key /*device [E]*/, const int64_t* other /*device [E]*/,
                       int64_t E, int64_t N /*key range*/, int64_t N_other /*other range*/,
                       int32_t* indptr /*device [N+1]*/, int32_t* indices /*device [E]*/,
                       int32_t* eid /*nullable, device [E]*/, float* norm_key /*nullable, device [N]*/,
+                      float* norm_other /*nullable, device [N_other]*/,
                       int norm_mode, int32_t heavy_thresh, int32_t chunk,
                       int32_t* heavy_rows, int32_t* heavy_chunk_ptr, int64_t capacity, void* ws,
                       size_t ws_bytes, int32_t* meta /*device [3], zeroed*/, void* stream);

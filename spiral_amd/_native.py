@@ -31,8 +31,9 @@ _SIGNATURES = {
     "spmi_coo_to_csr": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
                                 c_vp, c_vp]),
     "spmi_snapshot_csr_workspace_bytes": (c_sz, [c_i64, c_i64]),
-    "spmi_snapshot_csr": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_i32, c_i32,
-                                  c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp]),
+    "spmi_snapshot_csr_norm_other_supported": (c_int, [c_i64, c_i64, c_i64]),
+    "spmi_snapshot_csr": (c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i32,
+                                  c_i32, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "spmi_csr_prefix_workspace_bytes": (c_sz, [c_i64]),
     "spmi_csr_prefix": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
                                 c_vp, c_vp]),

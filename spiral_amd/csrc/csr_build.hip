@@ -150,18 +150,61 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const KeyT* __rest
     hist[static_cast<size_t>(d) * n_tiles + blockIdx.x] = s_hist[d];
 }
 
+// The first pass of a snapshot build reads both id arrays anyway (the scatter carries the
+// other endpoint along), so the pass that groups the OTHER endpoints into buckets of 4096
+// nodes for their degree count rides on it: this kernel makes both tile histograms in one
+// read of the two int64 arrays.
+__global__ __launch_bounds__(kThreads) void radix_hist_dual_kernel(
+    const int64_t* __restrict__ keys, const int64_t* __restrict__ other, int64_t E, uint32_t N,
+    uint32_t n_other, int shift, int bits, int shift2, int bits2, uint32_t* __restrict__ hist,
+    uint32_t* __restrict__ hist2, int n_tiles, int32_t* status) {
+  __shared__ uint32_t s_hist[kMaxDigits];
+  __shared__ uint32_t s_hist2[kMaxDigits];
+  const int ndig = 1 << bits, ndig2 = 1 << bits2;
+  const uint32_t mask = ndig - 1, mask2 = ndig2 - 1;
+  for (int d = threadIdx.x; d < kMaxDigits; d += kThreads) s_hist[d] = s_hist2[d] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile;
+  int64_t raw[kKeysPerThread], raw2[kKeysPerThread];
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = base + j * kThreads + threadIdx.x;
+    raw[j] = keys[i < E ? i : E - 1];
+    raw2[j] = other[i < E ? i : E - 1];
+  }
+#pragma unroll
+  for (int j = 0; j < kKeysPerThread; ++j) {
+    const int64_t i = base + j * kThreads + threadIdx.x;
+    if (i < E) {
+      atomicAdd(&s_hist[(checked_key(raw[j], N, status) >> shift) & mask], 1u);
+      atomicAdd(&s_hist2[(checked_key(raw2[j], n_other, status) >> shift2) & mask2], 1u);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < ndig; d += kThreads)
+    hist[static_cast<size_t>(d) * n_tiles + blockIdx.x] = s_hist[d];
+  for (int d = threadIdx.x; d < ndig2; d += kThreads)
+    hist2[static_cast<size_t>(d) * n_tiles + blockIdx.x] = s_hist2[d];
+}
+
 // ---- pass kernel 2: one workgroup per digit scans that digit's tile counts ------
 // A wave owns a contiguous quarter of the row and walks it in strips of 64 consecutive
 // counts, one per lane (a load or store instruction covers 256 contiguous bytes), eight
 // strips in flight at a time; the running sum travels in a register.  With a million tiles'
 // worth of edges a thread-contiguous split of the row (every lane of a load in a cache line of
 // its own) took 0.16 ms per pass.
+// Workgroups from `split` on scan the rows of a second histogram (the dual first pass).
 __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist,
                                                               int n_tiles,
-                                                              uint32_t* __restrict__ totals) {
+                                                              uint32_t* __restrict__ totals,
+                                                              uint32_t* __restrict__ hist2 = nullptr,
+                                                              uint32_t* __restrict__ totals2 = nullptr,
+                                                              int split = 1 << 30) {
   __shared__ uint32_t s_wave[kWaves];
   constexpr int kStrips = 8;
-  uint32_t* row = hist + static_cast<size_t>(blockIdx.x) * n_tiles;
+  const bool second = static_cast<int>(blockIdx.x) >= split;
+  const int digit = second ? static_cast<int>(blockIdx.x) - split : static_cast<int>(blockIdx.x);
+  uint32_t* row = (second ? hist2 : hist) + static_cast<size_t>(digit) * n_tiles;
   const int lane = lane_id();
   const int wave = wave_id();
   const int span = ((n_tiles + kWaves - 1) / kWaves + 63) / 64 * 64;
@@ -205,21 +248,30 @@ __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restri
       run += __shfl(incl, 63);
     }
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = total;
+  if (threadIdx.x == 0) (second ? totals2 : totals)[digit] = total;
 }
 
 // ---- pass kernel 3: stable scatter ------------------------------------------------
 // NVAL 32-bit values travel with each key: value 0 is the other endpoint of the edge,
 // value 1 the original edge position.  FIRST: keys and value 0 come from the caller's
 // int64 arrays (range-checked) and value 1 is the position itself.
-template <typename KeyT, bool FIRST, int NVAL>
+// What the dual first pass adds to the scatter: where the other endpoints go, grouped (in any
+// order) by their bucket of 2^shift2 nodes.
+struct OtherBuckets {
+  uint32_t* keys_out;
+  const uint32_t* hist;
+  const uint32_t* totals;
+  int shift, bits;
+};
+
+template <typename KeyT, bool FIRST, int NVAL, bool DUAL = false>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const KeyT* __restrict__ other_in,
     const uint32_t* __restrict__ v0_in, const uint32_t* __restrict__ v1_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ v0_out, uint32_t* __restrict__ v1_out,
     int64_t E, uint32_t N, uint32_t n_other, int shift, int bits,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, int n_tiles,
-    int32_t* status) {
+    int32_t* status, OtherBuckets ob = OtherBuckets{}) {
   __shared__ uint32_t s_cnt[kWaves][kMaxDigits];
   __shared__ uint32_t s_dstart[kMaxDigits];
   __shared__ uint32_t s_goff[kMaxDigits];
@@ -315,6 +367,44 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
       keys_out[g] = k;
       if constexpr (NVAL >= 1) v0_out[g] = s_v0[i];
       if constexpr (NVAL >= 2) v1_out[g] = s_v1[i];
+    }
+  }
+
+  if constexpr (DUAL && NVAL >= 1) {
+    // the other endpoints of this tile (range-checked above, still in registers), grouped by
+    // bucket without order: count, scan, next free slot per digit, staged in LDS, run by run out
+    __shared__ uint32_t s_cursor2[kMaxDigits];
+    __shared__ uint32_t s_dstart2[kMaxDigits];
+    __shared__ uint32_t s_goff2[kMaxDigits];
+    const int ndig2 = 1 << ob.bits;
+    const uint32_t mask2 = ndig2 - 1;
+    if (tid < ndig2) s_cursor2[tid] = 0;
+    __syncthreads();   // also: every thread is done reading s_keys
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j)
+      if (wave_base + j * 64 + lane < E) atomicAdd(&s_cursor2[(val0[j] >> ob.shift) & mask2], 1u);
+    __syncthreads();
+    const uint32_t dstart2 = block_exclusive_scan(tid < ndig2 ? s_cursor2[tid] : 0u, s_wave, &unused);
+    const uint32_t gbase2 = block_exclusive_scan(tid < ndig2 ? ob.totals[tid] : 0u, s_wave, &unused);
+    if (tid < ndig2) {
+      s_dstart2[tid] = dstart2;
+      s_cursor2[tid] = dstart2;
+      s_goff2[tid] = gbase2 + ob.hist[static_cast<size_t>(tid) * n_tiles + blockIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kKeysPerThread; ++j)
+      if (wave_base + j * 64 + lane < E)
+        s_keys[atomicAdd(&s_cursor2[(val0[j] >> ob.shift) & mask2], 1u)] = val0[j];
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < kKeysPerThread; ++j) {
+      const int i = j * kThreads + tid;
+      if (i < tile_count) {
+        const uint32_t k = s_keys[i];
+        const uint32_t d = (k >> ob.shift) & mask2;
+        ob.keys_out[s_goff2[d] + (static_cast<uint32_t>(i) - s_dstart2[d])] = k;
+      }
     }
   }
 }
@@ -1118,19 +1208,31 @@ size_t spmi_snapshot_csr_workspace_bytes(int64_t E, int64_t N) {
     const int n_buckets = static_cast<int>((N + kRows - 1) >> kLow);
     const size_t e4 = spmi::align_up(sizeof(uint32_t) * (size_t)E, 256);
     const size_t table = sizeof(uint32_t) * kRowWords * (size_t)bucket_build_grid(E, n_buckets);
-    bytes = std::max(bytes, 4 * e4 + sort_scratch_bytes(E, N) + bucket_layout_bytes(E, n_buckets) + table);
+    // 5 e4: two key buffers, one buffer per value, the grouped other endpoints of the dual pass;
+    // twice the sort scratch: the dual pass keeps a second tile histogram
+    bytes = std::max(bytes, 5 * e4 + 2 * sort_scratch_bytes(E, N) + bucket_layout_bytes(E, n_buckets) + table);
   }
   return bytes;
 }
 
+int spmi_snapshot_csr_norm_other_supported(int64_t E, int64_t N, int64_t N_other) {
+  // the other side's normaliser rides on the build when the build has ONE pass on the top bits
+  // (N <= 2^20) and the other side has at most 256 buckets of 4096 nodes
+  return bucket_build_applies(E, N) && N <= (static_cast<int64_t>(kFastBuckets) << kLow) && N_other >= 1 &&
+         N_other <= (int64_t{1} << (kCountLow + 8));
+}
+
 int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64_t N, int64_t N_other,
-                      int32_t* indptr, int32_t* indices, int32_t* eid, float* norm_key, int norm_mode,
-                      int32_t heavy_thresh, int32_t chunk, int32_t* heavy_rows, int32_t* heavy_chunk_ptr,
+                      int32_t* indptr, int32_t* indices, int32_t* eid, float* norm_key, float* norm_other,
+                      int norm_mode, int32_t heavy_thresh, int32_t chunk, int32_t* heavy_rows, int32_t* heavy_chunk_ptr,
                       int64_t capacity, void* ws, size_t ws_bytes, int32_t* meta, void* stream) {
   if (int rc = check_sizes(E, N, "spmi_snapshot_csr")) return rc;
   SPMI_REQUIRE(meta && indptr, SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: null indptr/meta");
-  SPMI_REQUIRE(!norm_key || norm_mode == SPMI_NORM_RSQRT || norm_mode == SPMI_NORM_RECIP, SPMI_ERR_INVALID_ARG,
-               "spmi_snapshot_csr: bad norm_mode %d", norm_mode);
+  SPMI_REQUIRE((!norm_key && !norm_other) || norm_mode == SPMI_NORM_RSQRT || norm_mode == SPMI_NORM_RECIP,
+               SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: bad norm_mode %d", norm_mode);
+  SPMI_REQUIRE(!norm_other || spmi_snapshot_csr_norm_other_supported(E, N, N_other), SPMI_ERR_UNSUPPORTED,
+               "spmi_snapshot_csr: norm_other is not available for E=%lld N=%lld N_other=%lld "
+               "(see spmi_snapshot_csr_norm_other_supported)", (long long)E, (long long)N, (long long)N_other);
   SPMI_REQUIRE(heavy_rows && heavy_chunk_ptr && heavy_thresh >= 1 && chunk >= 1 && capacity >= 2,
                SPMI_ERR_INVALID_ARG, "spmi_snapshot_csr: bad plan arguments");
   SPMI_REQUIRE(ws_bytes >= spmi_snapshot_csr_workspace_bytes(E, N), SPMI_ERR_WORKSPACE,
@@ -1168,6 +1270,11 @@ int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64
   const size_t hist_bytes = spmi::align_up(sizeof(uint32_t) * kMaxDigits * (size_t)n_tiles, 256);
   uint32_t* totals = reinterpret_cast<uint32_t*>(q + hist_bytes);
   q += sort_scratch_bytes(E, N);
+  uint32_t* hist2 = reinterpret_cast<uint32_t*>(q);
+  uint32_t* totals2 = reinterpret_cast<uint32_t*>(q + hist_bytes);
+  q += sort_scratch_bytes(E, N);
+  uint32_t* other_grouped = reinterpret_cast<uint32_t*>(q);
+  q += e4;
   const size_t nb_bytes = spmi::align_up(sizeof(int32_t) * (size_t)(n_buckets + 1), 256);
   int32_t* bstart = reinterpret_cast<int32_t*>(q);
   uint32_t* seg_base = reinterpret_cast<uint32_t*>(q + nb_bytes);
@@ -1175,10 +1282,35 @@ int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64
   uint32_t* table = reinterpret_cast<uint32_t*>(q + bucket_layout_bytes(E, n_buckets));
   int32_t* status = meta;
   const dim3 grid(n_tiles), block(kThreads);
+  // the dual first pass: the other endpoints grouped into buckets of 4096 nodes on the side
+  const int n_buckets2 = static_cast<int>((N_other + (1 << kCountLow) - 1) >> kCountLow);
+  int bits2 = 1;
+  while ((1 << bits2) < n_buckets2) ++bits2;
+  OtherBuckets ob{other_grouped, hist2, totals2, kCountLow, bits2};
   int shift = kLow;
   for (int ps = 0; ps < passes; ++ps) {
     const int out = (passes - 1 - ps) & 1, in = out ^ 1;
     const int pb = pass_bits[ps];
+    if (ps == 0 && norm_other) {
+      radix_hist_dual_kernel<<<grid, block, 0, st>>>(key, other, E, (uint32_t)N, (uint32_t)N_other, shift, pb,
+                                                     kCountLow, bits2, hist, hist2, n_tiles, status);
+      SPMI_CHECK_LAUNCH("radix_hist_dual");
+      radix_scan_kernel<<<dim3((1 << pb) + (1 << bits2)), block, 0, st>>>(hist, n_tiles, totals, hist2, totals2,
+                                                                          1 << pb);
+      SPMI_CHECK_LAUNCH("radix_scan(dual)");
+      if (eid) {
+        radix_scatter_kernel<int64_t, true, 2, true><<<grid, block, 0, st>>>(
+            key, other, nullptr, nullptr, keys_ab[out], v0_ab[out], v1_ab[out], E, (uint32_t)N, (uint32_t)N_other,
+            shift, pb, hist, totals, n_tiles, status, ob);
+      } else {
+        radix_scatter_kernel<int64_t, true, 1, true><<<grid, block, 0, st>>>(
+            key, other, nullptr, nullptr, keys_ab[out], v0_ab[out], nullptr, E, (uint32_t)N, (uint32_t)N_other,
+            shift, pb, hist, totals, n_tiles, status, ob);
+      }
+      SPMI_CHECK_LAUNCH("radix_scatter(dual)");
+      shift += pb;
+      continue;
+    }
     if (ps == 0) {
       radix_hist_kernel<int64_t><<<grid, block, 0, st>>>(key, E, (uint32_t)N, shift, pb, hist, n_tiles, status);
     } else {
@@ -1242,6 +1374,11 @@ int spmi_snapshot_csr(const int64_t* key, const int64_t* other, int64_t E, int64
   plan_finish_kernel<<<1, kPlanThreads, 0, st>>>(indptr, chunk, heavy_rows, heavy_chunk_ptr, capacity - 1,
                                              meta + 1);
   SPMI_CHECK_LAUNCH("plan_finish(bucket)");
+  if (norm_other) {
+    bucket_count_kernel<<<n_buckets2, kCountThreads, 0, st>>>(other_grouped, totals2, nullptr, N_other, nullptr,
+                                                              norm_other, norm_mode);
+    SPMI_CHECK_LAUNCH("bucket_count(other)");
+  }
   return SPMI_OK;
 }
 

@@ -65,6 +65,7 @@ class CSR:
         self._pending = pending  # (pinned int32[3], event, device int32[3]) until ready()
         self._partial: Dict[int, torch.Tensor] = {}
         self._norms: Dict[int, torch.Tensor] = {}  # normaliser of the rows, per mode
+        self._other_norms: Dict[int, torch.Tensor] = {}  # normaliser of the other side, where the build made it
 
     def ready(self) -> "CSR":
         if self._pending is not None:
@@ -98,6 +99,9 @@ class CSR:
     def degrees(self) -> torch.Tensor:
         """int64 row degrees, like DGLGraph.in_degrees()."""
         return (self.indptr[1:] - self.indptr[:-1]).to(torch.int64)
+
+    def other_norm(self, mode: int) -> Optional[torch.Tensor]:
+        return self._other_norms.get(mode)
 
     def norm(self, mode: int) -> torch.Tensor:
         out = self._norms.get(mode)
@@ -139,12 +143,16 @@ def _fetch_meta(meta: torch.Tensor):
 
 def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
               heavy_thresh: int = HEAVY_THRESH, chunk: int = HEAVY_CHUNK,
-              want_eid: bool = False, defer: bool = False, norm_mode: Optional[int] = None) -> CSR:
+              want_eid: bool = False, defer: bool = False, norm_mode: Optional[int] = None,
+              other_norm: bool = False) -> CSR:
     """COO -> CSR grouped by `key` plus the aggregation plan, one library call.  The status word
     and the plan sizes cost one host sync: here, or with `defer` at the CSR's first `ready()`.
     Edge ids travel through the sort only when `want_eid` (edge weights / edge features need
     them; plain GCN does not).  `norm_mode` (0 or 1): the normaliser of the key side is written
-    by the same kernels that write the row pointers and kept on the CSR (`CSR.norm(mode)`)."""
+    by the same kernels that write the row pointers and kept on the CSR (`CSR.norm(mode)`).
+    `other_norm`: also the normaliser of the OTHER side in that mode (out-degree based, beside a
+    by-destination CSR), where the library can make it in the same pass over the id arrays
+    (`CSR.other_norm(mode)`, None where it cannot: the caller counts the id column instead)."""
     nv.require_cuda(key, other)
     key, other = _i64(key).contiguous(), _i64(other).contiguous()
     dev = key.device
@@ -155,6 +163,9 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
         indices = torch.empty(e, dtype=torch.int32, device=dev)
         eid = torch.empty(e, dtype=torch.int32, device=dev) if want_eid else None
         norm = torch.empty(n_key, dtype=torch.float32, device=dev) if norm_mode is not None else None
+        onorm = None
+        if other_norm and norm_mode is not None and lib.spmi_snapshot_csr_norm_other_supported(e, n_key, n_other):
+            onorm = torch.empty(n_other, dtype=torch.float32, device=dev)
         cap = e // heavy_thresh + 2
         heavy_rows = torch.empty(cap, dtype=torch.int32, device=dev)
         heavy_ptr = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -162,7 +173,7 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
         ws_bytes = lib.spmi_snapshot_csr_workspace_bytes(e, n_key)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         nv.check(lib.spmi_snapshot_csr(nv.ptr(key), nv.ptr(other), e, n_key, n_other, nv.ptr(indptr),
-                                       nv.ptr(indices), nv.ptr(eid), nv.ptr(norm),
+                                       nv.ptr(indices), nv.ptr(eid), nv.ptr(norm), nv.ptr(onorm),
                                        0 if norm_mode is None else int(norm_mode), heavy_thresh, chunk,
                                        nv.ptr(heavy_rows), nv.ptr(heavy_ptr), cap, nv.ptr(ws), ws_bytes,
                                        nv.ptr(meta), nv.stream()), "spmi_snapshot_csr")
@@ -171,6 +182,8 @@ def build_csr(key: torch.Tensor, other: torch.Tensor, n_key: int, n_other: int,
               chunk, pending)
     if norm is not None:
         csr._norms[int(norm_mode)] = norm
+    if onorm is not None:
+        csr._other_norms[int(norm_mode)] = onorm
     return csr if defer else csr.ready()
 
 
@@ -520,8 +533,9 @@ class SnapshotGraph(NormalisedAdjacency):
             else:
                 # GraphConv's default norm ('both') wants degree^-1/2 of the rows: written by the
                 # kernels that write the row pointers, for nothing
+                # (and, when no backward pass will build the by-source CSR, the source side's too)
                 self._csr = build_csr(self._dst, self._src, self._n, self._n, want_eid=want_eid,
-                                      defer=True, norm_mode=0)
+                                      defer=True, norm_mode=0, other_norm=not torch.is_grad_enabled())
         return self._csr.ready() if wait else self._csr
 
     def csr_t(self, want_eid: bool = False, wait: bool = True) -> CSR:
@@ -548,7 +562,9 @@ class SnapshotGraph(NormalisedAdjacency):
                 # that uses this normaliser collects its verdict.  Its source column (int32,
                 # ids clamped into range) is counted instead of a second pass over the int64 ids.
                 csr = self.csr(wait=False)
-                if self._out_deg is None and self._table is None:
+                if csr.other_norm(mode) is not None:
+                    self._norms[key] = csr.other_norm(mode)
+                elif self._out_deg is None and self._table is None:
                     self._norms[key] = norm_from_ids32(csr.indices, self._n, mode)
                 else:
                     self._norms[key] = norm_from_degree(self.out_degrees(), mode)

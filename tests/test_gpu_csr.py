@@ -223,8 +223,13 @@ def test_one_call_build_equals_the_three_calls(dev, n, e, k_dst, mode):
     for want_eid in (False, True):
         indptr, indices, eid, norm, rows, ptr, counts, status = _old_three_calls(dst, src, n, n, want_eid, mode, dev)
         assert status == 0
-        csr = G.build_csr(dst, src, n, n, want_eid=want_eid, norm_mode=mode)
+        csr = G.build_csr(dst, src, n, n, want_eid=want_eid, norm_mode=mode, other_norm=True)
         assert torch.equal(csr.indptr, indptr) and torch.equal(csr.indices, indices)
+        # the other side's normaliser, made by the same pass where the library offers it
+        assert (csr.other_norm(mode) is not None) == bool(nv.lib().spmi_snapshot_csr_norm_other_supported(e, n, n))
+        if csr.other_norm(mode) is not None:
+            d = torch.bincount(src, minlength=n).to(torch.float32).clamp_(min=1)
+            assert torch.equal(csr.other_norm(mode), 1.0 / d.sqrt() if mode == 0 else 1.0 / d)
         assert (csr.eid is None) == (not want_eid) and (eid is None or torch.equal(csr.eid, eid))
         assert torch.equal(csr.norm(mode), norm)
         assert [csr.n_heavy, csr.n_chunks] == counts
