@@ -806,7 +806,10 @@ def main():
                        "resident_snapshots": n_snap,
                        "step": ("COO->CSR+norm, weight GRU x2, 2x GraphConv (bf16 rows), "
                                 if kind == "evolve_bf16" else
-                                f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu), "
+                                f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu"
+                                + (": X W first, then the aggregation; on this in = out tie DGL "
+                                   "aggregates first -- same result within 1e-5, tested against the "
+                                   "DGL-order oracle" if f == w['hidden'] else "") + "), "
                                 f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
                        "head": "one-kernel inference MLP" if MLP.FUSE_EVAL and not train else "torch layers",

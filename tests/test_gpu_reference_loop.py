@@ -10,8 +10,9 @@ Bars.  First step (identical parameters and state): loss 1e-5 relative, every pa
 gradient 1e-5 of that gradient's largest entry.  Later steps: Adam divides the gradient by
 its own magnitude, so the first updates are +-lr whatever the gradient's size and a rounding
 difference in a near-zero gradient entry moves a weight by up to 2 lr; losses are held to
-1e-3 relative over both epochs and the memories to 1e-3 of their largest entry (measured:
-about 1e-5 and 1e-5)."""
+1e-5 relative over both epochs (measured 1.5e-7), the memories to 1e-4 of their largest entry
+(measured 7e-8 for the GRU, 3e-6 for the LSTM) and the parameters to 2e-4 absolute (measured
+6e-8 / 1.7e-5); the test prints what it measures."""
 import copy
 
 import numpy as np
@@ -97,15 +98,18 @@ def _check_first_step_gradients(mine, theirs, mlp):
     zero = set(_zero_gradient_biases(mlp, len(theirs) - len(list(mlp.parameters()))))
     assert zero, "the head is expected to hold Linear -> BatchNorm1d pairs"
     bad = []
+    worst = 0.0
     for i, (p, q) in enumerate(zip(mine, theirs)):
         assert p.grad is not None and q.grad is not None, i
         if i in zero:
             r = max(float(p.grad.abs().max()), float(q.grad.abs().max())) / gmax
         else:
             r = float((p.grad.cpu() - q.grad).abs().max()) / float(q.grad.abs().max())
+        worst = max(worst, r)
         if not r <= 1e-5:
             bad.append((i, tuple(q.shape), f"{r:.2e}"))
     assert not bad, bad
+    return worst
 
 
 @pytest.mark.parametrize("kind", ["gru", "lstm"])
@@ -148,21 +152,32 @@ def test_two_epochs_of_the_reference_loop_with_adam(dev, kind):
                                   torch.from_numpy(feat_next[:n, -1]))
             loss_ref.backward()
             if first:
-                assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-5
-                _check_first_step_gradients(_gpu_params(model), ref.params, ref.mlp)
+                first_loss = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+                assert first_loss < 1e-5, first_loss
+                first_grad = _check_first_step_gradients(_gpu_params(model), ref.params, ref.mlp)
                 first = False
             opt.step()                                                        # :101
             opt_ref.step()
             losses.append(loss.item())
             losses_ref.append(loss_ref.item())
     assert len(losses) == 2 * (n_snapshot - 7)
-    for a, b in zip(losses, losses_ref):
-        assert abs(a - b) / abs(b) < 1e-3, (losses, losses_ref)
+    # After the first step the parameters have been through Adam, which turns rounding differences
+    # of near-zero gradient entries into steps of +-lr, so these bars are wider than 1e-5: losses
+    # 1e-5 (measured 1.5e-7), memory 1e-4 (measured 7e-8 / 3e-6), parameters 2e-4 absolute
+    # (measured 6e-8 / 1.7e-5).  What is measured is printed (profiles/r03_parity_measured.txt).
+    loss_err = max(abs(a - b) / abs(b) for a, b in zip(losses, losses_ref))
+    assert loss_err < 1e-5, (loss_err, losses, losses_ref)
     mem = model.decoder.memory_h.memory.cpu()
-    assert float((mem - ref.mem_h).abs().max() / ref.mem_h.abs().max()) < 1e-3
+    mem_err = float((mem - ref.mem_h).abs().max() / ref.mem_h.abs().max())
+    assert mem_err < 1e-4, mem_err
     # parameters after 2 x 3 Adam steps; the zero-gradient biases are left out: Adam turns their
     # rounding noise into +-lr steps on both sides (they do not reach the output in train mode)
     zero = set(_zero_gradient_biases(ref.mlp, len(ref.params) - len(list(ref.mlp.parameters()))))
+    par_err = 0.0
     for i, (p, q) in enumerate(zip(_gpu_params(model), ref.params)):
         if i not in zero:
-            assert float((p.detach().cpu() - q.detach()).abs().max()) < 1e-3, i
+            par_err = max(par_err, float((p.detach().cpu() - q.detach()).abs().max()))
+            assert par_err < 2e-4, (i, par_err)
+    print(f"reference loop, {kind}: first-step loss {first_loss:.1e} and gradients {first_grad:.1e} (bar 1e-5); "
+          f"losses of all steps {loss_err:.1e} (bar 1e-5), memory {mem_err:.1e} (bar 1e-4), "
+          f"parameters {par_err:.1e} absolute (bar 2e-4)")
