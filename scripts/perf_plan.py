@@ -44,9 +44,9 @@ def all_gather_into_tensor(out, inp, group=None):
 
 
 def all_to_all_single(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
-    if out.dim() == 2 and out.dtype == torch.int64:        # requests: (row in the owner's block, count)
+    if out.dim() == 2 and out.shape[1] == 2:               # requests: (row in the owner's block, count)
         out.copy_(inp)
-        out[:, 0].remainder_(state["n_local"])
+        out[:, 0].remainder_(state["n_local"])             # a row of THIS rank's block, as a peer would ask
     else:
         out.copy_(inp.reshape(out.shape))
 
@@ -82,3 +82,21 @@ for world in ranks:
           f"{shard.plan.n_remote} of {n - (hi - lo)}; plan {med['plan']:.3f} ms, CSR build {med['csr_build']:.3f} ms, "
           f"out-degree exchange (local part) {med['out_degree']:.3f} ms", flush=True)
     del shard, s, d, keep
+
+if os.environ.get("PLAN_PROFILE") == "1":   # the kernels of one plan, longest first
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        bounds = par.edge_balanced_bounds(deg, ranks[-1])
+        part = par.RowPartition(n, bounds, ranks[-1] // 2, ranks[-1])
+        lo, hi = part.block()
+        keep = (dst >= lo) & (dst < hi)
+        s, d = src[keep].contiguous(), dst[keep].contiguous()
+        state.update(world=ranks[-1], rank=ranks[-1] // 2, n_local=hi - lo)
+        par.ShardedSnapshot(s, d, part)     # workspace made here
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        shard = par.ShardedSnapshot(s, d, part)
+        torch.cuda.synchronize()
+        print(f"second plan, wall {1e3 * (time.perf_counter() - t0):.3f} ms")
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))

@@ -238,16 +238,22 @@ class CumulativeCSR:
         return out
 
 
-def degree(ids: torch.Tensor, n: int, validated: bool = False) -> torch.Tensor:
-    """deg[v] = occurrences of v in ids (int64), by keys-only sort + run boundaries.
-    `validated` says the caller already knows every id is inside [0, n), so the call does
-    not wait for the device to report the range check."""
+def degree(ids: torch.Tensor, n: int, validated: bool = False, out: Optional[torch.Tensor] = None
+           ) -> torch.Tensor:
+    """deg[v] = occurrences of v in ids (int64): ids grouped into buckets of 4096 nodes and
+    counted in LDS (n <= 2^24), keys-only sort + run boundaries beyond.  `validated` says the
+    caller does not need the range check reported here (an id outside [0, n) is clamped, never
+    dereferenced), so the call does not wait for the device.  `out`: a contiguous int64 [n]
+    tensor to write into (a caller that counts every snapshot keeps one)."""
     nv.require_cuda(ids)
     ids = _i64(ids).contiguous()
     dev = ids.device
     lib = nv.lib()
     with torch.cuda.device(dev):
-        out = torch.empty(n, dtype=torch.int64, device=dev)
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=dev)
+        elif out.dtype != torch.int64 or out.numel() != n or not out.is_contiguous():
+            raise nv.SpmiError("degree(out=...) expects a contiguous int64 tensor of n elements")
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         ws_bytes = lib.spmi_degree_workspace_bytes(ids.numel(), n)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)

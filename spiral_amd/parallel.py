@@ -101,7 +101,8 @@ class PlanWorkspace:
     """What an exchange plan needs over the whole node range, allocated once per partition and
     device and reused by every snapshot (a plan leaves it as it found it):
 
-    mark    int32[N]  zero between plans; 1 at the remote ids a plan's edges name
+    deg     int64[N]  how many of the plan's edges leave every node (scratch)
+    mark    bool[N]   the remote ids a plan's edges name (scratch)
     csum    int32[N]  inclusive scan of mark (scratch)
     colmap  int64[N]  table row of a node id: the own block's entries never change, a plan
                       overwrites exactly the remote entries it reads afterwards
@@ -111,7 +112,8 @@ class PlanWorkspace:
 
     def __init__(self, part: RowPartition, device: torch.device):
         lo, hi = part.block()
-        self.mark = torch.zeros(part.n, dtype=torch.int32, device=device)
+        self.deg = torch.empty(part.n, dtype=torch.int64, device=device)
+        self.mark = torch.zeros(part.n, dtype=torch.bool, device=device)
         self.csum = torch.empty(part.n, dtype=torch.int32, device=device)
         self.colmap = torch.full((part.n,), -1, dtype=torch.int64, device=device)
         self.colmap[lo:hi] = torch.arange(hi - lo, dtype=torch.int64, device=device)
@@ -135,8 +137,9 @@ class ExchangePlan:
     holds slice k of the rows needed from every peer, peers in rank order, rows in ascending
     id order.  `cols` gives every edge its row of that table.
 
-    Cost per snapshot: a mark and a scan over the node range in persistent buffers (no
-    allocation of that size), ONE host round trip (the P x P matrix of row counts, gathered on
+    Cost per snapshot: one count of the edges' sources over the node range (the degree kernels,
+    which also gives every named row its number of edges here), a scan over the marks, both in
+    persistent buffers (no allocation of that size), ONE host round trip (the P x P matrix of row counts, gathered on
     the device and copied once: it holds what this rank needs from every peer and what every
     peer needs from it), and one all-to-all of the requests.  A request carries the row number
     inside its owner's block and this rank's count of edges that leave the row, so the owners
@@ -159,9 +162,15 @@ class ExchangePlan:
 
         # distinct remote sources by mark and scan over the node range (no sort), their counts
         # per owner read off the scan at the block ends
+        # edges of this rank that leave every node: the marks of the named rows and, later, the
+        # counts the out-degrees are added up from.  An id outside the node range is clamped by
+        # the count and stopped by the bounds check of the gather through colmap below.
+        self._own_partial = None
         if world > 1:
-            ws.mark.index_fill_(0, src, 1)
-            ws.mark[lo:hi] = 0                                    # own rows stay where they are
+            kernels.degree(src, part.n, validated=True, out=ws.deg)
+            self._own_partial = ws.deg[lo:hi].clone()
+            torch.gt(ws.deg, 0, out=ws.mark)
+            ws.mark[lo:hi] = False                                # own rows stay where they are
             torch.cumsum(ws.mark, 0, dtype=torch.int32, out=ws.csum)
             upto = ws.csum.index_select(0, ws.end_idx).to(torch.int64) * ws.end_ok
             need_dev = torch.diff(upto, prepend=upto.new_zeros(1))
@@ -172,7 +181,6 @@ class ExchangePlan:
             wanted = counts[:, rank].tolist()                     # rows rank p wants from this rank
             self.n_remote = sum(need)
             uniq = torch.nonzero_static(ws.mark, size=self.n_remote).reshape(-1)  # ascending ids
-            ws.mark.zero_()
         else:
             need, wanted, self.n_remote = [0], [0], 0
             uniq = torch.empty(0, dtype=torch.int64, device=dev)
@@ -203,11 +211,10 @@ class ExchangePlan:
         self._uniq, self._table_row = uniq, table_row
         ws.colmap[uniq] = table_row
         self.cols = ws.colmap.index_select(0, src)            # table row of every edge's source
-        # global id of every table row (own block first), e.g. to look up per-node vectors
-        order = torch.empty(self.n_remote, dtype=torch.int64, device=dev)
-        order[table_row - self.n_local] = uniq
-        self.table_ids = torch.cat([torch.arange(lo, hi, dtype=torch.int64, device=dev), order])
-        self._partial_out = self._out_degree_table = None
+        self._table_ids = self._out_degree_table = None
+        # this rank's edges out of every named row (a single rank names none and counts on demand)
+        self._uniq_partial = ws.deg.index_select(0, uniq) if world > 1 else None
+        self._src = src if world == 1 else None
 
         # tell every owner which of its rows are wanted here, and how many edges leave them here
         self.send_counts = [[0] * world for _ in range(self.stages)]
@@ -215,10 +222,10 @@ class ExchangePlan:
         self._asked = self._asked_count = self.send_index
         if world > 1:
             request = uniq - ws.bounds_t[part.owner(uniq)]    # row inside the owner's block
-            message = torch.stack([request, self._partial().index_select(0, table_row)], 1)
-            asked = torch.empty(sum(wanted), 2, dtype=torch.int64, device=dev)
+            message = torch.stack([request, self._uniq_partial], 1).to(torch.int32)   # both below 2^31
+            asked = torch.empty(sum(wanted), 2, dtype=torch.int32, device=dev)
             dist.all_to_all_single(asked, message, wanted, need, group=group)
-            self._asked, self._asked_count = asked[:, 0].contiguous(), asked[:, 1].contiguous()
+            self._asked, self._asked_count = asked[:, 0].to(torch.int64), asked[:, 1].to(torch.int64)
             # reorder the requests batch-major, the order the rows are sent in
             starts = [sum(wanted[:p]) for p in range(world)]
             pieces = []
@@ -248,12 +255,17 @@ class ExchangePlan:
         b = torch.tensor(self.batch_start[1:-1], dtype=torch.int64, device=cols.device)
         return torch.bucketize(cols, b, right=True)
 
-    def _partial(self) -> torch.Tensor:
-        """Edges of this rank that leave every table row (int64 [n_table]).  The ids were
-        range-checked by the gather through colmap, so the count waits for no status word."""
-        if self._partial_out is None:
-            self._partial_out = kernels.degree(self.cols, self.n_table, validated=True).to(torch.int64)
-        return self._partial_out
+    @property
+    def table_ids(self) -> torch.Tensor:
+        """Global id of every row of the source table (own block first), e.g. to look up
+        per-node vectors; made on first use (layers with an exchange never need it)."""
+        if self._table_ids is None:
+            lo, hi = self.part.block()
+            dev = self._uniq.device
+            order = torch.empty(self.n_remote, dtype=torch.int64, device=dev)
+            order[self._table_row - self.n_local] = self._uniq
+            self._table_ids = torch.cat([torch.arange(lo, hi, dtype=torch.int64, device=dev), order])
+        return self._table_ids
 
     def out_degree_table(self) -> torch.Tensor:
         """Out-degree in the whole graph (int64) of every row of this rank's source table.
@@ -262,11 +274,10 @@ class ExchangePlan:
         their own counts and answer every request with the total: one more all-to-all of
         n_remote numbers, against an all-reduce over the whole node range."""
         if self._out_degree_table is None:
-            partial = self._partial()
             if self.part.world == 1:
-                self._out_degree_table = partial
+                self._out_degree_table = kernels.degree(self._src, self.part.n, validated=True).to(torch.int64)
             else:
-                own = partial[: self.n_local].clone()
+                own = self._own_partial.clone()
                 own.index_add_(0, self._asked, self._asked_count)   # integer adds: order-free
                 reply = own.index_select(0, self._asked)
                 back = torch.empty(self.n_remote, dtype=torch.int64, device=own.device)
