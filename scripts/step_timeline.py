@@ -3,8 +3,8 @@ gap in front of each, so host stalls show up next to the kernels that wait for t
 
     python scripts/step_timeline.py gpurun_out/prof/bench_kernel_trace.csv [--step -2]
 
-A step is delimited by the first kernel of the snapshot build (the 64-bit histogram of the
-by-destination sort)."""
+A step is delimited by the first kernel of the snapshot build (the histogram over both id
+columns); --marker/--every select another delimiter (a kernel that runs `every` times a step)."""
 import argparse
 import csv
 import re
@@ -20,7 +20,8 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--step", type=int, default=-2, help="which step to print (index into the list of steps)")
-    ap.add_argument("--marker", default="radix_hist_kernel<long", help="substring of a step's first kernel")
+    ap.add_argument("--marker", default="radix_hist_dual_kernel", help="substring of a step's first kernel")
+    ap.add_argument("--every", type=int, default=1, help="launches of the marker kernel per step")
     args = ap.parse_args()
     rows = []
     with open(args.trace) as f:
@@ -28,8 +29,9 @@ def main() -> None:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     starts = [i for i, r in enumerate(rows) if args.marker in r[2]]
-    # two sorts per step start with that kernel (by destination, out-degree): keep every other one
-    starts = starts[::2]
+    starts = starts[::args.every]
+    if len(starts) < 2:
+        raise SystemExit(f"fewer than two launches of a kernel named *{args.marker}* in {args.trace}")
     lo = starts[args.step]
     hi = starts[args.step + 1] if args.step + 1 < len(starts) and args.step != -1 else len(rows)
     t0, prev_end, busy = rows[lo][0], rows[lo][0], 0
