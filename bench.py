@@ -820,9 +820,11 @@ def main():
                                      "bf16x3": "fp32 results from bf16 matrix cores: operands split exactly in "
                                                "three bf16 pieces, six piece products per term",
                                      "fp32": "fp32 matrix instruction"}[ops.CELL_GEMM],
-                       "recurrent_kernel": ("spmi_gru_rows_fwd (gate weights of a 32-unit slice resident in LDS, "
-                                            "node memory trades tables)"
-                                            if not train and kind == "gcn_gru" and ops.USE_GRU_ROWS
+                       "recurrent_kernel": ((("spmi_gru_rows_fwd_saved (the same kernel keeping the gate values; "
+                                              "the node memory adopts each layer's output)") if train else
+                                             ("spmi_gru_rows_fwd (gate weights of a 32-unit slice resident in "
+                                              "LDS, node memory trades tables)"))
+                                            if kind == "gcn_gru" and ops.USE_GRU_ROWS
                                             and ops.CELL_GEMM == "f16x3" and w["rnn_hidden"] == 128
                                             and w["hidden"] == 128 else "row-tile kernel / autograd path"),
                        "exchange": exchange_note or (args.exchange if multi and not train else

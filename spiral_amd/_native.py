@@ -63,6 +63,7 @@ _SIGNATURES = {
                                   c_vp, c_vp]),
     "spmi_gru_gate_bwd": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "spmi_gru_gate_bwd_packed": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "spmi_gru_gate_bwd_packed_q": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "spmi_lstm_gate_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                    c_vp, c_int, c_vp, c_vp]),
     "spmi_lstm_gate_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
@@ -85,6 +86,8 @@ _SIGNATURES = {
     "spmi_gru_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_gru_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                   c_int, c_vp]),
+    "spmi_gru_rows_fwd_saved": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
+                                        c_vp, c_int, c_vp]),
     "spmi_rnn_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_rnn_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                   c_int, c_vp]),

@@ -45,6 +45,7 @@ struct GruRowsArgs {
   float* h_out;
   int64_t M;
   int x_bounded;
+  float4* saved;  // SAVE kernels: [M][H] of (r, z, n, W_hn h + b_hn), the gate values a backward pass needs
 };
 
 __device__ __forceinline__ float rcpf_(float v) { return __builtin_amdgcn_rcpf(v); }
@@ -113,7 +114,9 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[4], const f16x8& p0, co
 
 // KT = I / 16 = H / 16 K-steps per operand; H / 32 column slices.
 // XB: the caller vouches for |x| < 2^15 (no magnitude pass, no scaling code).
-template <int KT, bool XB>
+// SAVE: the step is tracked for a backward pass: the gate values of every state element leave
+// as one 16-byte store from the lane that computed them (32 lanes cover 512 contiguous bytes).
+template <int KT, bool XB, bool SAVE = false>
 __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
   constexpr int H = KT * 16;
   constexpr int GH = 3 * H;
@@ -316,6 +319,12 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    float4* sv = nullptr;
+    bool sv_whole = true;
+    if constexpr (SAVE) {
+      sv = p.saved + row0 * H + voff;  // element e: + ((e & 3) + 8 (e >> 2)) * H
+      sv_whole = row0 + 32 <= p.M;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       // r and z from one reciprocal: with p = 1 + e^-a, q = 1 + e^-b and i = 1/(p q),
@@ -331,6 +340,10 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
       const float hn = acc[3][e] + b_hn;
       const float n = tanhf_(acc[2][e] + b_in + r * hn);
       hy[e] = n + z * (hy[e] - n);
+      if constexpr (SAVE) {
+        const int ur = (e & 3) + 8 * (e >> 2);
+        if (sv_whole || row0 + ur + 4 * lh < p.M) sv[ur * H] = make_float4(r, z, n, hn);
+      }
     }
     prev_row0 = row0;
     tile = next;
@@ -636,9 +649,12 @@ template <int KT>
 int launch(const GruRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep;
   static_assert(lds <= 160 * 1024, "weight slice does not fit LDS");
-  auto kern = a.x_bounded ? gru_rows_kernel<KT, true> : gru_rows_kernel<KT, false>;
+  auto kern = a.saved ? (a.x_bounded ? gru_rows_kernel<KT, true, true> : gru_rows_kernel<KT, false, true>)
+                      : (a.x_bounded ? gru_rows_kernel<KT, true> : gru_rows_kernel<KT, false>);
   SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, true>), lds);  // each use keeps its own record
   SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, false>), lds);
+  SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, true, true>), lds);
+  SPMI_RAISE_LDS_LIMIT((gru_rows_kernel<KT, false, true>), lds);
   // One workgroup per CU (the slice image takes most of its LDS); a small batch gets as many
   // row groups as it has tiles for, in whole sets of 8 XCDs x NS slices.
   constexpr int NS = KT / 2;
@@ -657,9 +673,9 @@ extern "C" {
 
 int spmi_gru_rows_supported(int64_t I, int64_t H) { return I == 128 && H == 128; }
 
-int spmi_gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
-                      const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
-                      float* h_out, int x_bounded, void* stream) {
+static int gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                        const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
+                        float* h_out, float* saved, int x_bounded, void* stream) {
   SPMI_REQUIRE(spmi_gru_rows_supported(I, H), SPMI_ERR_UNSUPPORTED,
                "spmi_gru_rows_fwd: needs I = H = 128 (I=%lld H=%lld)", (long long)I, (long long)H);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_gru_rows_fwd: bad M=%lld",
@@ -683,12 +699,33 @@ int spmi_gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih,
     const uintptr_t xbytes = (static_cast<uintptr_t>(M - 1) * ldx + I) * sizeof(float);
     SPMI_REQUIRE(x0 + xbytes <= o0 || o0 + bytes <= x0, SPMI_ERR_INVALID_ARG,
                  "spmi_gru_rows_fwd: h_out overlaps x");
+    if (saved) {
+      const uintptr_t s0 = reinterpret_cast<uintptr_t>(saved), sbytes = 4 * bytes;
+      SPMI_REQUIRE((s0 & 15u) == 0, SPMI_ERR_INVALID_ARG, "spmi_gru_rows_fwd_saved: saved must be 16-byte aligned");
+      SPMI_REQUIRE((s0 + sbytes <= o0 || o0 + bytes <= s0) && (s0 + sbytes <= i0 || i0 + bytes <= s0) &&
+                       (s0 + sbytes <= x0 || x0 + xbytes <= s0),
+                   SPMI_ERR_INVALID_ARG, "spmi_gru_rows_fwd_saved: saved overlaps x, h_in or h_out");
+    }
   }
   GruRowsArgs a{};
   a.x = x; a.ldx = ldx;
   a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
   a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.h_out = h_out; a.M = M; a.x_bounded = x_bounded;
+  a.saved = reinterpret_cast<float4*>(saved);
   return launch<8>(a, spmi::as_stream(stream));
+}
+
+int spmi_gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                      const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
+                      float* h_out, int x_bounded, void* stream) {
+  return gru_rows_fwd(x, ldx, I, ws_ih, ws_hh, b_ih, b_hh, h_in, M, H, h_out, nullptr, x_bounded, stream);
+}
+
+int spmi_gru_rows_fwd_saved(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                            const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
+                            float* h_out, float* saved, int x_bounded, void* stream) {
+  SPMI_REQUIRE(saved || M == 0, SPMI_ERR_INVALID_ARG, "spmi_gru_rows_fwd_saved: saved is null");
+  return gru_rows_fwd(x, ldx, I, ws_ih, ws_hh, b_ih, b_hh, h_in, M, H, h_out, saved, x_bounded, stream);
 }
 
 int spmi_rnn_rows_supported(int64_t I, int64_t H) { return I == 128 && H == 128; }

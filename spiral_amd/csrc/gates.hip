@@ -188,6 +188,39 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_packed_kernel(const float* _
   if (g_h) st<VEC>(g_h + e.m * H + e.j, dh);
 }
 
+// The same packed gradients from gate values kept per state element, (r, z, n, W_hn h + b_hn) as
+// one float4 (what the whole-table forward of cell_rows.hip writes), and the old state read from
+// the matrix it came from.  A thread handles four consecutive hidden units of one node.
+__global__ __launch_bounds__(kThreads) void gru_bwd_packed_q_kernel(const float* __restrict__ g_out,
+                                                                    const float4* __restrict__ saved,
+                                                                    const float* __restrict__ h_old,
+                                                                    int64_t ldh, int64_t M, int H,
+                                                                    float* __restrict__ g4) {
+  Elem e;
+  if (!decode<4>(M, H, &e)) return;
+  const Pack<4> g = ld<4>(g_out + e.m * H + e.j);
+  const Pack<4> h = ld<4>(h_old + e.m * ldh + e.j);
+  const float4* s = saved + e.m * H + e.j;
+  const float4 q[4] = {s[0], s[1], s[2], s[3]};
+  Pack<4> dar, daz, dan, danr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // the same expressions, in the same order, as gru_bwd_kernel
+    const float r = q[i].x, z = q[i].y, n = q[i].z, hn = q[i].w;
+    const float dn = g.v[i] * (1.0f - z);
+    const float dz = g.v[i] * (h.v[i] - n);
+    dan.v[i] = dn * (1.0f - n * n);
+    daz.v[i] = dz * z * (1.0f - z);
+    const float dr = dan.v[i] * hn;
+    dar.v[i] = dr * r * (1.0f - r);
+    danr.v[i] = dan.v[i] * r;
+  }
+  const int64_t g0 = e.m * 4 * H + e.j;
+  st<4>(g4 + g0, dan);
+  st<4>(g4 + g0 + H, dar);
+  st<4>(g4 + g0 + 2 * H, daz);
+  st<4>(g4 + g0 + 3 * H, danr);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void lstm_fwd_kernel(
     const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ b_ih,
@@ -373,6 +406,23 @@ int spmi_gru_gate_bwd_packed(const float* gh_out, const float* saved, int64_t M,
   const bool v4 = (H % 4 == 0) && all_aligned16({gh_out, saved, g4, g_h});
   SPMI_LAUNCH_VEC(gru_bwd_packed_kernel, v4, M, H, spmi::as_stream(stream), gh_out, saved, M,
                   static_cast<int>(H), g4, g_h);
+  return SPMI_OK;
+}
+
+int spmi_gru_gate_bwd_packed_q(const float* gh_out, const float* saved, const float* h_old, int64_t ldh,
+                               int64_t M, int64_t H, float* g4, void* stream) {
+  if (int rc = check_mh(M, H, "spmi_gru_gate_bwd_packed_q")) return rc;
+  if (M == 0) return SPMI_OK;
+  SPMI_REQUIRE(gh_out && saved && h_old && g4, SPMI_ERR_INVALID_ARG, "spmi_gru_gate_bwd_packed_q: null pointer");
+  SPMI_REQUIRE(H % 4 == 0 && ldh >= H && ldh % 4 == 0 && all_aligned16({gh_out, saved, h_old, g4}),
+               SPMI_ERR_INVALID_ARG,
+               "spmi_gru_gate_bwd_packed_q: H and ldh must be multiples of 4 and the pointers 16-byte aligned");
+  const int64_t work = M * (H / 4);
+  const int64_t blocks = (work + kThreads - 1) / kThreads;
+  SPMI_REQUIRE(blocks < (int64_t{1} << 31), SPMI_ERR_UNSUPPORTED, "spmi_gru_gate_bwd_packed_q: too many elements");
+  gru_bwd_packed_q_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, spmi::as_stream(stream)>>>(
+      gh_out, reinterpret_cast<const float4*>(saved), h_old, ldh, M, static_cast<int>(H), g4);
+  SPMI_CHECK_LAUNCH("gru_bwd_packed_q");
   return SPMI_OK;
 }
 

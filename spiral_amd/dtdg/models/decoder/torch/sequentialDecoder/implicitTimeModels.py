@@ -73,6 +73,13 @@ class NodeMemory:
 
     @property
     def memory(self) -> torch.Tensor:
+        """The (n_layers, n_nodes, hidden_d) table.  After tracked whole-table steps the state
+        lives in one matrix per layer (`set_layers`); the first reader of the table stacks them
+        into a table of its own, so nothing written to the table reaches tensors an autograd
+        graph still holds."""
+        if self._layers is not None:
+            self._memory = torch.stack(self._layers)
+            self._layers = None
         return self._memory
 
     @memory.setter
@@ -80,7 +87,24 @@ class NodeMemory:
         """A table assigned from outside (a restored checkpoint, a test fixture) has unknown
         magnitudes until `bounded()` looks at it."""
         self._memory = table
+        self._layers = None
         self._bounded = None
+
+    def layer(self, k: int) -> torch.Tensor:
+        """The [n_nodes, hidden_d] state of layer k, to be READ only: it may be the output of a
+        tracked step that an autograd graph holds.  Writers go through `memory`."""
+        return self._layers[k] if self._layers is not None else self._memory[k]
+
+    def rows(self) -> int:
+        return (self._layers[0] if self._layers is not None else self._memory).shape[-2]
+
+    def set_layers(self, layers) -> None:
+        """The new state of every node, one detached [n_nodes, hidden_d] matrix per layer,
+        becomes the memory as it is (no copy).  The matrices are never written afterwards: the
+        whole-table steps write their results elsewhere and everything else sees a stacked copy
+        (`memory`).  Boundedness carries over (see X_BOUND)."""
+        self._layers = [t.detach() for t in layers]
+        self._memory = None
 
     def bounded(self, wait: bool = True) -> bool:
         """Whether every stored state is below X_BOUND in magnitude.  The cell kernels keep the
@@ -90,7 +114,7 @@ class NodeMemory:
         the answer is "no" (callers then take the path that assumes nothing) until a later
         call finds it landed."""
         if self._bounded is None:
-            m = self._memory
+            m = self.memory
             if m.numel() == 0:
                 self._bounded = True
             elif wait or not m.is_cuda:
@@ -132,7 +156,7 @@ class NodeMemory:
 
     @property
     def device(self):
-        return self.memory.device
+        return (self._layers[0] if self._layers is not None else self._memory).device
 
     def to(self, device, **kwargs):
         device = torch.device(device) if device is not None else None
@@ -270,11 +294,27 @@ class GRU(SequentialDecoder):
         # cannot update rows in place, so the new state goes to the memory's second table and
         # the two tables trade places afterwards; the returned rows are the new state itself.
         inner_bounded = mem.bounded(wait=False)  # layers k > 0 read the state of layer k - 1
-        whole = (ids is None and x.shape[0] == mem.memory.shape[1]
+        every_node = (ids is None and x.shape[0] == mem.rows()
+                      and self._layer_params(0)[0].shape[1] == x.shape[1])
+        params = [self._layer_params(k) for k in range(self.n_layers)]
+        tracked = torch.is_grad_enabled() and (x.requires_grad or any(
+            t is not None and t.requires_grad for ps in params for t in ps))
+        if every_node and tracked and all(ops.gru_rows_tracked_ok(x if k == 0 else mem.layer(k), params[k][1])
+                                          for k in range(self.n_layers)):
+            # Every node, under autograd: the same kernel with the gate values kept.  Each layer's
+            # new state is a tensor of its own (the graph's), and the memory adopts it as it is.
+            new = []
+            for k in range(self.n_layers):
+                h = ops.gru_rows_tracked(x, *params[k], mem.layer(k), x_bounded=k > 0 and inner_bounded)
+                new.append(h)
+                x = self._between_layers(h, k)
+            if self.training_mode:
+                mem.set_layers(new)
+            return x
+        whole = (every_node and not tracked
                  and all(ops.gru_rows_ok(x if k == 0 else mem.memory[k], self._layer_params(k)[1],
                                          *self._layer_params(k)[::2], self._layer_params(k)[3])
-                         for k in range(self.n_layers))
-                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+                         for k in range(self.n_layers)))
         if whole:
             new = mem.spare() if self.training_mode else None
             for k in range(self.n_layers):

@@ -1068,6 +1068,28 @@ def lstm_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, c_in:
 GRU_PACKED_BACKWARD = True
 
 
+def _gru_grads_from_packed(ctx, g4, xd, h_old, w_ih):
+    """(g_x, g_w_ih, g_w_hh, g_b_ih, g_b_hh) of a GRU layer from its packed gate gradients
+    g4 = [n | r | z | n*r] ([M, 4H], see GruCell._backward_packed), the layer's input rows and
+    its old state."""
+    hd = g4.shape[1] // 4
+    g_i, g_hh = g4[:, : 3 * hd], g4[:, hd:]
+    nrz = lambda t: torch.cat([t[2 * hd:], t[: 2 * hd]])      # torch's r, z, n -> n, r, z
+    rzn = lambda t: torch.cat([t[hd:], t[:hd]])               # and back
+    g_x = None
+    if ctx.needs_input_grad[0]:
+        w_nrz = nrz(w_ih.detach())                             # [3H, I]
+        g_x = gemm_rows(g_i, w_nrz.t()) if _gemm_rows_ok(g_i, 3 * hd, w_ih.shape[1]) else g_i @ w_nrz
+    need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+    need_bhh = ctx.has_bias and ctx.needs_input_grad[4]
+    g_wih, g_bih = _weight_and_bias_grad(g_i, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
+    g_whh, g_bhh = _weight_and_bias_grad(g_hh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
+    if g_wih is not None:
+        g_wih = rzn(g_wih)
+    g_bih = rzn(g_bih) if (g_bih is not None and ctx.has_bias and ctx.needs_input_grad[3]) else None
+    return g_x, g_wih, g_whh, g_bih, g_bhh
+
+
 class GruCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, ids, mem_write):
@@ -1104,22 +1126,7 @@ class GruCell(torch.autograd.Function):
         with torch.cuda.device(g_h.device):
             nv.check(nv.lib().spmi_gru_gate_bwd_packed(nv.ptr(g_h), nv.ptr(saved), m, hd, nv.ptr(g4),
                                                        None, nv.stream()), "spmi_gru_gate_bwd_packed")
-        g_i, g_hh = g4[:, : 3 * hd], g4[:, hd:]
-        h_old = saved[:, 4 * hd:]
-        nrz = lambda t: torch.cat([t[2 * hd:], t[: 2 * hd]])      # torch's r, z, n -> n, r, z
-        rzn = lambda t: torch.cat([t[hd:], t[:hd]])               # and back
-        g_x = None
-        if ctx.needs_input_grad[0]:
-            w_nrz = nrz(w_ih.detach())                             # [3H, I]
-            g_x = gemm_rows(g_i, w_nrz.t()) if _gemm_rows_ok(g_i, 3 * hd, w_ih.shape[1]) else g_i @ w_nrz
-        need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        need_bhh = ctx.has_bias and ctx.needs_input_grad[4]
-        g_wih, g_bih = _weight_and_bias_grad(g_i, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
-        g_whh, g_bhh = _weight_and_bias_grad(g_hh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
-        if g_wih is not None:
-            g_wih = rzn(g_wih)
-        g_bih = rzn(g_bih) if (g_bih is not None and ctx.has_bias and ctx.needs_input_grad[3]) else None
-        return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
+        return _gru_grads_from_packed(ctx, g4, xd, saved[:, 4 * hd:], w_ih) + (None, None, None)
 
     @staticmethod
     def backward(ctx, g_h):
@@ -1149,6 +1156,69 @@ class GruCell(torch.autograd.Function):
         if not (ctx.has_bias and ctx.needs_input_grad[3]):
             g_bih = None
         return g_x, g_wih, g_whh, g_bih, g_bhh, None, None, None
+
+
+def gru_rows_tracked_ok(x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+    """The whole-table GRU kernel takes this layer as a tracked step (`gru_rows_tracked`): the
+    conditions of `gru_rows_ok` without the one that nothing be tracked."""
+    return (USE_FUSED_CELLS and USE_GRU_ROWS and GRU_PACKED_BACKWARD and CELL_GEMM == "f16x3" and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(nv.lib().spmi_gru_rows_supported(x.shape[1], w_hh.shape[1])))
+
+
+class GruRowsTracked(torch.autograd.Function):
+    """One GRU layer step over every row of the state matrix `h_in` [M, H] on the kernel that
+    keeps the gate weights in LDS, with the gate values kept for the backward pass.  The new
+    state is the returned tensor (storage of its own); `h_in` is read, never written, and is
+    what the backward pass reads the old state from."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_in, x_bounded):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        _check_cell_args(xd, h_in, None)
+        if h_in.shape != (m, hd):
+            raise nv.SpmiError("gru_rows_tracked: h_in must be the [M, H] state of the rows of x")
+        need_grad = _needs_grad(ctx, 5)
+        saved = torch.empty(m, hd, 4, dtype=torch.float32, device=x.device) if need_grad else None
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
+        ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)
+        with torch.cuda.device(x.device):
+            if saved is None:
+                nv.check(nv.lib().spmi_gru_rows_fwd(
+                    nv.ptr(xd), xd.stride(0), xd.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+                    nv.ptr(b_hh), nv.ptr(h_in), m, hd, nv.ptr(h_out), int(x_bounded), nv.stream()),
+                    "spmi_gru_rows_fwd")
+            else:
+                nv.check(nv.lib().spmi_gru_rows_fwd_saved(
+                    nv.ptr(xd), xd.stride(0), xd.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+                    nv.ptr(b_hh), nv.ptr(h_in), m, hd, nv.ptr(h_out), nv.ptr(saved), int(x_bounded),
+                    nv.stream()), "spmi_gru_rows_fwd_saved")
+        ctx.save_for_backward(xd, w_ih, w_hh, saved, h_in)
+        ctx.has_bias = b_ih is not None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, g_h):
+        xd, w_ih, w_hh, saved, h_in = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g4 = torch.empty(m, 4 * hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_gru_gate_bwd_packed_q(
+                nv.ptr(g_h), nv.ptr(saved), nv.ptr(h_in), h_in.stride(0), m, hd, nv.ptr(g4), nv.stream()),
+                "spmi_gru_gate_bwd_packed_q")
+        return _gru_grads_from_packed(ctx, g4, xd, h_in, w_ih) + (None, None)
+
+
+def gru_rows_tracked(x, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, x_bounded: bool = False) -> torch.Tensor:
+    """One GRU layer step for every row under autograd: the state matrix `h_in` [M, H] is read
+    (and kept for the backward pass: it must not be written before that pass has run), the new
+    state comes back as a tensor of its own."""
+    return _apply_tracked(GruRowsTracked, (x, w_ih, w_hh, b_ih, b_hh), x, w_ih, w_hh, b_ih, b_hh, h_in,
+                          bool(x_bounded))
 
 
 class LstmCell(torch.autograd.Function):

@@ -229,3 +229,84 @@ def test_gru_backward_with_packed_gate_gradients(dev, m, i, h):
         for got, ref, name in zip(run(packed), want, ("x", "w_ih", "w_hh", "b_ih", "b_hh")):
             err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
             assert err < 1e-5, (packed, name, err)
+
+
+@pytest.mark.parametrize("m", [6000, 33, 4096 + 17])
+def test_tracked_whole_table_gru_step(dev, m):
+    """The whole-table GRU kernel as a tracked step (gate values kept per state element, the old
+    state read from the matrix it came from) against torch.nn.GRUCell in float64: new state and
+    the gradients of x, both weights and both biases within 1e-5 of each tensor's largest entry;
+    the state matrix it read is left as it was."""
+    i = h = 128
+    w_ih, w_hh, b_ih, b_hh = _params(3, i, h, dev, 21)
+    gen = torch.Generator().manual_seed(m)
+    x0 = torch.randn(m, i, generator=gen).to(dev)
+    h0 = (torch.randn(m, h, generator=gen) * 0.5).to(dev)
+    wgt = torch.randn(m, h, generator=gen).to(dev) * 1e-3
+    leaves = [t.clone().requires_grad_() for t in (x0, w_ih, w_hh, b_ih, b_hh)]
+    h_in = h0.clone()
+    assert ops.gru_rows_tracked_ok(leaves[0], leaves[2])
+    out = ops.gru_rows_tracked(leaves[0], *leaves[1:], h_in)
+    assert out.data_ptr() != h_in.data_ptr() and torch.equal(h_in, h0)
+    (out * wgt).sum().backward()
+
+    cell = torch.nn.GRUCell(i, h).double()
+    with torch.no_grad():
+        for p, t in zip((cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh), (w_ih, w_hh, b_ih, b_hh)):
+            p.copy_(t.double().cpu())
+    xr = x0.double().cpu().requires_grad_()
+    ref = cell(xr, h0.double().cpu())
+    (ref * wgt.double().cpu()).sum().backward()
+    err = float((out.detach().double().cpu() - ref.detach()).abs().max())
+    assert err < 1e-5, err
+    want = [xr.grad, cell.weight_ih.grad, cell.weight_hh.grad, cell.bias_ih.grad, cell.bias_hh.grad]
+    for got, r, name in zip([t.grad for t in leaves], want, ("x", "w_ih", "w_hh", "b_ih", "b_hh")):
+        e = float((got.double().cpu() - r).abs().max()) / float(r.abs().max())
+        assert e < 1e-5, (name, e)
+    # the same numbers as the inference kernel (one loop nest, one epilogue)
+    with torch.no_grad():
+        plain = ops.gru_rows(x0, w_ih, w_hh, b_ih, b_hh, h0, torch.empty_like(h0))
+    assert torch.equal(plain, out.detach())
+
+
+def test_tracked_whole_table_steps_through_the_decoder(dev):
+    """Two tracked steps of the GRU decoder over every node (the train loop's shape): the memory
+    adopts each step's output without a copy, a loss summed over both steps goes backward through
+    both graphs (nothing a graph holds is overwritten by the second step), and the table read
+    afterwards equals the second step's state.  Against the same decoder on the row-tile path."""
+    from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder.implicitTimeModels import GRU
+    from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP
+
+    n, hd = 5000, 128
+
+    def run(rows_kernel):
+        old, ops.USE_GRU_ROWS = ops.USE_GRU_ROWS, rows_kernel
+        try:
+            torch.manual_seed(5)
+            dec = GRU(hd, hd, n, 2, MLP(hd, [16], dropout=0.0)).to(dev)
+            dec.train()
+            torch.manual_seed(6)
+            dec.memory_h.reset_state()
+            dec.memory_h = dec.memory_h.to(dev)
+            xs = [torch.randn(n, hd, device=dev, generator=torch.Generator(dev).manual_seed(40 + t)) for t in range(2)]
+            loss = 0
+            for x in xs:
+                out = dec((x, list(range(n))))
+                loss = loss + out.pow(2).mean()
+            adopted = dec.memory_h._layers is not None
+            loss.backward()
+            grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
+            return float(loss.detach()), grads, dec.memory_h.memory.clone(), adopted
+        finally:
+            ops.USE_GRU_ROWS = old
+
+    loss_a, grads_a, mem_a, adopted_a = run(True)
+    loss_b, grads_b, mem_b, adopted_b = run(False)
+    assert adopted_a and not adopted_b
+    assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_b)
+    assert float((mem_a - mem_b).abs().max()) < 1e-5
+    # against the model's largest gradient: the bias in front of a train-mode BatchNorm has a
+    # gradient of exactly zero in exact arithmetic and rounding noise here
+    scale = max(float(g.abs().max()) for g in grads_b.values())
+    for k in grads_b:
+        assert float((grads_a[k] - grads_b[k]).abs().max()) / scale < 1e-5, k
