@@ -573,6 +573,21 @@ int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K
                       int accumulate, float* col_sum_a /*nullable [M]*/,
                       float* col_sum_b /*nullable [N]*/, int fp32_instruction, void* ws,
                       size_t ws_bytes, void* stream);
+/* Two such products of one shape over the same K rows in ONE launch: C0 = A0^T B0 and
+ * C1 = A1^T B1 (bf16-piece products, col_sum_a0 / col_sum_a1 nullable).  The waves of a chunk
+ * of K run side by side for both, so columns the operands share are read from memory once: the
+ * two weight gradients of a GRU layer (implicitTimeModels.py:185-187 under autograd) are
+ * dW_ih = G[:, 0:3H]^T x and dW_hh = G[:, H:4H]^T h over one packed gate-gradient matrix G
+ * whose middle 2H columns both read (3 GB instead of 4 per layer at 1M rows, H = 128).
+ * M and N multiples of 128, M * N <= 512 * 512 (spmi_gemm_tn_pair_supported); operands 16-byte
+ * aligned, leading dimensions multiples of 4.  Bit-reproducible; the split of K differs from
+ * the single product's, so the sums agree with it to fp32 rounding, not bit for bit. */
+int spmi_gemm_tn_pair_supported(int64_t M, int64_t N);
+size_t spmi_gemm_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int spmi_gemm_tn_pair_sums(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, const float* A1,
+                           int64_t lda1, const float* B1, int64_t ldb1, int64_t K, int64_t M, int64_t N,
+                           float* C0, int64_t ldc0, float* C1, int64_t ldc1, float* col_sum_a0 /*nullable [M]*/,
+                           float* col_sum_a1 /*nullable [M]*/, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Output head in inference, one kernel: the MLP of

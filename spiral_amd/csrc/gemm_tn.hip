@@ -326,16 +326,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_partial_x3_kernel(
 //  * The 256 accumulators take the whole accumulation register file: one wave per SIMD.
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
+// One launch may carry a second product of the same shape over the same rows (`second`): the
+// waves of one chunk of K then run side by side for both, so that columns the two products
+// share (the r and z gate gradients of a GRU layer, read by dW_ih and by dW_hh) come from
+// memory once.
+struct TnProblem {
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  float* partial;
+  float* sum_a_partial;
+  float* sum_b_partial;
+};
+
 __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
-    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, int64_t K,
-    int M, int N, int64_t k_chunk, int n_chunks, float* __restrict__ partial,
-    float* __restrict__ sum_a_partial, float* __restrict__ sum_b_partial) {
+    TnProblem first, TnProblem second, int n_problems, int64_t K, int M, int N, int64_t k_chunk,
+    int n_chunks) {
   const int lane = threadIdx.x & 63;
   const int m_blocks = M / 128, blocks = m_blocks * (N / 128);
   // wave-uniform by construction; said so, row bases stay in scalar registers
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kWaves + (threadIdx.x >> 6));
-  const int chunk = w / blocks, blk = w % blocks;
+  const int per_chunk = blocks * n_problems;
+  const int chunk = w / per_chunk;
   if (chunk >= n_chunks) return;
+  const int which = (w % per_chunk) / blocks, blk = w % blocks;
+  const TnProblem& pr = which ? second : first;
+  const float* __restrict__ A = pr.A;
+  const float* __restrict__ B = pr.B;
+  const int64_t lda = pr.lda, ldb = pr.ldb;
+  float* __restrict__ partial = pr.partial;
+  float* __restrict__ sum_a_partial = pr.sum_a_partial;
+  float* __restrict__ sum_b_partial = pr.sum_b_partial;
   const int m0 = (blk % m_blocks) * 128, n0 = (blk / m_blocks) * 128;
   const int64_t k_begin = static_cast<int64_t>(chunk) * k_chunk;
   const int64_t k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
@@ -531,12 +553,12 @@ Shape plan(int64_t M, int64_t N, int64_t K, bool pieces) {
 // of K per wave.
 bool wide_shape(int64_t M, int64_t N) { return M % 128 == 0 && N % 128 == 0 && M * N <= 512 * 512; }
 
-Shape plan_wide(int64_t M, int64_t N, int64_t K) {
+Shape plan_wide(int64_t M, int64_t N, int64_t K, int n_problems = 1) {
   Shape s{};
   s.mt = s.nt = 4;
   s.m_strips = static_cast<int>(M / 128);
   s.n_tiles = static_cast<int>(N / 128);
-  const int64_t blocks = s.m_strips * s.n_tiles;
+  const int64_t blocks = static_cast<int64_t>(s.m_strips) * s.n_tiles * n_problems;
   // one wave per SIMD over the whole chip
   int64_t chunks = 1024 / blocks;
   const int64_t max_chunks = (K + 255) / 256;
@@ -551,6 +573,37 @@ int check_gemm_tn(int64_t M, int64_t N, int64_t K) {
   SPMI_REQUIRE(M >= 1 && N >= 1 && K >= 1 && M <= 4096 && N <= 4096 && K < (int64_t{1} << 40),
                SPMI_ERR_INVALID_ARG, "spmi_gemm_tn: bad sizes M=%lld N=%lld K=%lld (M, N <= 4096)",
                (long long)M, (long long)N, (long long)K);
+  return SPMI_OK;
+}
+
+// C = (accumulate ? C : 0) + sum over the chunks' partial products, and the operand column sums
+// by the same fixed-order reduction over vectors of M / N entries.
+int reduce_chunks(const float* partial, const float* pa, const float* pb, int n_chunks, int64_t M, int64_t N,
+                  float* C, int64_t ldc, int accumulate, float* col_sum_a, float* col_sum_b, hipStream_t st) {
+  const int64_t mn = M * N;
+  if (n_chunks >= 64) {
+    const unsigned blocks = static_cast<unsigned>((mn + 4 * kWaves - 1) / (4 * kWaves));
+    gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(partial, n_chunks, mn, (int)N, C, ldc, accumulate);
+  } else {
+    const unsigned blocks = static_cast<unsigned>((mn + kThreads - 1) / kThreads);
+    gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(partial, n_chunks, mn, (int)N, C, ldc, accumulate);
+  }
+  SPMI_CHECK_LAUNCH("gemm_tn_reduce");
+  const float* vec_src[2] = {pa, pb};
+  float* vec_dst[2] = {col_sum_a, col_sum_b};
+  const int64_t vec_len[2] = {M, N};
+  for (int v = 0; v < 2; ++v) {
+    if (!vec_dst[v]) continue;
+    const int64_t len = vec_len[v];
+    if (n_chunks >= 64) {
+      const unsigned blocks = static_cast<unsigned>((len + 4 * kWaves - 1) / (4 * kWaves));
+      gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(vec_src[v], n_chunks, len, (int)len, vec_dst[v], len, 0);
+    } else {
+      const unsigned blocks = static_cast<unsigned>((len + kThreads - 1) / kThreads);
+      gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(vec_src[v], n_chunks, len, (int)len, vec_dst[v], len, 0);
+    }
+    SPMI_CHECK_LAUNCH("gemm_tn_reduce(sums)");
+  }
   return SPMI_OK;
 }
 
@@ -609,8 +662,9 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
                                                                s.n_tiles, pa, pb)
   if (wide) {
     const unsigned wgs = static_cast<unsigned>((s.m_strips * s.n_tiles * s.n_chunks + kWaves - 1) / kWaves);
-    gemm_tn_partial_x3_wide_kernel<<<wgs, kThreads, 0, st>>>(A, lda, B, ldb, K, (int)M, (int)N, s.k_chunk,
-                                                             s.n_chunks, partial, pa, pb);
+    const TnProblem one{A, lda, B, ldb, partial, pa, pb};
+    gemm_tn_partial_x3_wide_kernel<<<wgs, kThreads, 0, st>>>(one, one, 1, K, (int)M, (int)N, s.k_chunk,
+                                                             s.n_chunks);
   } else if (pieces) {
     if (s.mt == 2 && s.nt == 2) SPMI_GEMM_TN_X3(2, 2);
     else if (s.mt == 2) SPMI_GEMM_TN_X3(2, 1);
@@ -622,36 +676,55 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
 #undef SPMI_GEMM_TN
 #undef SPMI_GEMM_TN_X3
   SPMI_CHECK_LAUNCH("gemm_tn_partial");
-  const int64_t mn = M * N;
-  if (s.n_chunks >= 64) {
-    const unsigned blocks = static_cast<unsigned>((mn + 4 * kWaves - 1) / (4 * kWaves));
-    gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(partial, s.n_chunks, mn, (int)N, C, ldc,
-                                                           accumulate);
-  } else {
-    const unsigned blocks = static_cast<unsigned>((mn + kThreads - 1) / kThreads);
-    gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(partial, s.n_chunks, mn, (int)N, C, ldc,
-                                                          accumulate);
-  }
-  SPMI_CHECK_LAUNCH("gemm_tn_reduce");
-  // the operand column sums: the same fixed-order chunk reduction over vectors of M / N entries
-  const float* vec_src[2] = {pa, pb};
-  float* vec_dst[2] = {col_sum_a, col_sum_b};
-  const int64_t vec_len[2] = {M, N};
-  for (int v = 0; v < 2; ++v) {
-    if (!vec_dst[v]) continue;
-    const int64_t len = vec_len[v];
-    if (s.n_chunks >= 64) {
-      const unsigned blocks = static_cast<unsigned>((len + 4 * kWaves - 1) / (4 * kWaves));
-      gemm_tn_reduce_kernel<16><<<blocks, kThreads, 0, st>>>(vec_src[v], s.n_chunks, len, (int)len,
-                                                             vec_dst[v], len, 0);
-    } else {
-      const unsigned blocks = static_cast<unsigned>((len + kThreads - 1) / kThreads);
-      gemm_tn_reduce_kernel<1><<<blocks, kThreads, 0, st>>>(vec_src[v], s.n_chunks, len, (int)len,
-                                                            vec_dst[v], len, 0);
-    }
-    SPMI_CHECK_LAUNCH("gemm_tn_reduce(sums)");
-  }
-  return SPMI_OK;
+  return reduce_chunks(partial, pa, pb, s.n_chunks, M, N, C, ldc, accumulate, col_sum_a, col_sum_b, st);
+}
+
+int spmi_gemm_tn_pair_supported(int64_t M, int64_t N) { return wide_shape(M, N) ? 1 : 0; }
+
+size_t spmi_gemm_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (!wide_shape(M, N) || K < 1) return 0;
+  const int chunks = plan_wide(M, N, K, 2).n_chunks;
+  return 2 * sizeof(float) * static_cast<size_t>(chunks) * (M * N + M + N);
+}
+
+int spmi_gemm_tn_pair_sums(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, const float* A1,
+                           int64_t lda1, const float* B1, int64_t ldb1, int64_t K, int64_t M, int64_t N,
+                           float* C0, int64_t ldc0, float* C1, int64_t ldc1, float* col_sum_a0,
+                           float* col_sum_a1, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_gemm_tn(M, N, K)) return rc;
+  SPMI_REQUIRE(wide_shape(M, N), SPMI_ERR_UNSUPPORTED,
+               "spmi_gemm_tn_pair_sums: M and N must be multiples of 128 with M*N <= 512*512 (M=%lld N=%lld)",
+               (long long)M, (long long)N);
+  SPMI_REQUIRE(A0 && B0 && A1 && B1 && C0 && C1 && ws, SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_tn_pair_sums: null pointer argument");
+  SPMI_REQUIRE(lda0 >= M && lda1 >= M && ldb0 >= N && ldb1 >= N && ldc0 >= N && ldc1 >= N, SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_tn_pair_sums: a leading dimension is too small");
+  SPMI_REQUIRE(lda0 % 4 == 0 && lda1 % 4 == 0 && ldb0 % 4 == 0 && ldb1 % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(A0) | reinterpret_cast<uintptr_t>(B0) |
+                     reinterpret_cast<uintptr_t>(A1) | reinterpret_cast<uintptr_t>(B1)) & 15u) == 0,
+               SPMI_ERR_INVALID_ARG,
+               "spmi_gemm_tn_pair_sums: operands must be 16-byte aligned with leading dimensions in multiples of 4");
+  SPMI_REQUIRE(lda0 < (int64_t{1} << 27) && ldb0 < (int64_t{1} << 27) && lda1 < (int64_t{1} << 27) &&
+                   ldb1 < (int64_t{1} << 27),
+               SPMI_ERR_UNSUPPORTED, "spmi_gemm_tn_pair_sums: leading dimension too large");
+  SPMI_REQUIRE(ws_bytes >= spmi_gemm_tn_pair_workspace_bytes(M, N, K), SPMI_ERR_WORKSPACE,
+               "spmi_gemm_tn_pair_sums: workspace %zu < required %zu", ws_bytes,
+               spmi_gemm_tn_pair_workspace_bytes(M, N, K));
+  const Shape s = plan_wide(M, N, K, 2);
+  hipStream_t st = spmi::as_stream(stream);
+  const size_t per_problem = static_cast<size_t>(s.n_chunks) * (M * N + M + N);
+  float* p0 = static_cast<float*>(ws);
+  float* p1 = p0 + per_problem;
+  float* sa0 = col_sum_a0 ? p0 + static_cast<size_t>(s.n_chunks) * M * N : nullptr;
+  float* sa1 = col_sum_a1 ? p1 + static_cast<size_t>(s.n_chunks) * M * N : nullptr;
+  const TnProblem first{A0, lda0, B0, ldb0, p0, sa0, nullptr};
+  const TnProblem second{A1, lda1, B1, ldb1, p1, sa1, nullptr};
+  const int64_t waves = static_cast<int64_t>(s.m_strips) * s.n_tiles * 2 * s.n_chunks;
+  gemm_tn_partial_x3_wide_kernel<<<static_cast<unsigned>((waves + kWaves - 1) / kWaves), kThreads, 0, st>>>(
+      first, second, 2, K, (int)M, (int)N, s.k_chunk, s.n_chunks);
+  SPMI_CHECK_LAUNCH("gemm_tn_partial(pair)");
+  if (int rc = reduce_chunks(p0, sa0, nullptr, s.n_chunks, M, N, C0, ldc0, 0, col_sum_a0, nullptr, st)) return rc;
+  return reduce_chunks(p1, sa1, nullptr, s.n_chunks, M, N, C1, ldc1, 0, col_sum_a1, nullptr, st);
 }
 
 }  // extern "C"

@@ -149,6 +149,37 @@ def _weight_and_bias_grad(dy: torch.Tensor, x: torch.Tensor, need_w: bool, need_
     return g_w, g_b
 
 
+def gemm_tn_pair_ok(a0: torch.Tensor, b0: torch.Tensor, a1: torch.Tensor, b1: torch.Tensor) -> bool:
+    """`gemm_tn_pair` takes these operands: two products of one shape over the same rows, tall
+    enough for the split-K kernel, whole 128 x 128 output blocks, layouts its loads accept."""
+    ts = (a0, b0, a1, b1)
+    return (GEMM_TN_MODE == "bf16x3" and a0.shape == a1.shape and b0.shape == b1.shape
+            and a0.shape[0] == b0.shape[0] >= GEMM_TN_MIN_ROWS
+            and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+                    and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in ts)
+            and bool(nv.lib().spmi_gemm_tn_pair_supported(a0.shape[1], b0.shape[1])))
+
+
+def gemm_tn_pair(a0: torch.Tensor, b0: torch.Tensor, a1: torch.Tensor, b1: torch.Tensor, sums: bool = False):
+    """(a0^T b0, a1^T b1[, a0.sum(0), a1.sum(0)]) in one launch (`gemm_tn_pair_ok` holds): the
+    column ranges a0 and a1 share are read from memory once."""
+    k, m = a0.shape
+    n = b0.shape[1]
+    lib = nv.lib()
+    with torch.cuda.device(a0.device):
+        c0 = torch.empty(m, n, dtype=torch.float32, device=a0.device)
+        c1 = torch.empty(m, n, dtype=torch.float32, device=a0.device)
+        s0 = torch.empty(m, dtype=torch.float32, device=a0.device) if sums else None
+        s1 = torch.empty(m, dtype=torch.float32, device=a0.device) if sums else None
+        ws_bytes = lib.spmi_gemm_tn_pair_workspace_bytes(m, n, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a0.device)
+        nv.check(lib.spmi_gemm_tn_pair_sums(
+            nv.ptr(a0), a0.stride(0), nv.ptr(b0), b0.stride(0), nv.ptr(a1), a1.stride(0), nv.ptr(b1),
+            b1.stride(0), k, m, n, nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), nv.ptr(ws), ws_bytes,
+            nv.stream()), "spmi_gemm_tn_pair_sums")
+    return (c0, c1, s0, s1) if sums else (c0, c1)
+
+
 # Projections of a tall matrix by a small weight: "f16x3" = libspmi's memory-speed kernel on
 # the fp16 matrix cores (three-plane operands, fp32-chain accuracy; rows of any finite
 # magnitude, they are scaled by a power of two in the kernel; weights within +-1023),
@@ -1066,6 +1097,8 @@ def lstm_rows(x: torch.Tensor, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, c_in:
 # GRU layers hand their gate gradients to the dense kernels as one [rows, 4H] matrix instead of
 # two [rows, 3H] ones (see GruCell._backward_packed).
 GRU_PACKED_BACKWARD = True
+# ... and take both weight gradients of a layer from one launch over that matrix (spmi_gemm_tn_pair_sums).
+GRU_PAIRED_WEIGHT_GRADS = True
 
 
 def _gru_grads_from_packed(ctx, g4, xd, h_old, w_ih):
@@ -1082,8 +1115,17 @@ def _gru_grads_from_packed(ctx, g4, xd, h_old, w_ih):
         g_x = gemm_rows(g_i, w_nrz.t()) if _gemm_rows_ok(g_i, 3 * hd, w_ih.shape[1]) else g_i @ w_nrz
     need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
     need_bhh = ctx.has_bias and ctx.needs_input_grad[4]
-    g_wih, g_bih = _weight_and_bias_grad(g_i, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
-    g_whh, g_bhh = _weight_and_bias_grad(g_hh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
+    if (GRU_PAIRED_WEIGHT_GRADS and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+            and gemm_tn_pair_ok(g_i, xd, g_hh, h_old)):
+        # both weight gradients from one launch: the r and z columns of g4 are read once
+        g_wih, g_whh, g_bih, g_bhh = gemm_tn_pair(g_i, xd, g_hh, h_old, sums=True)
+        if not need_b:
+            g_bih = None
+        if not need_bhh:
+            g_bhh = None
+    else:
+        g_wih, g_bih = _weight_and_bias_grad(g_i, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
+        g_whh, g_bhh = _weight_and_bias_grad(g_hh, h_old, ctx.needs_input_grad[2], need_bhh, dy_first=True)
     if g_wih is not None:
         g_wih = rzn(g_wih)
     g_bih = rzn(g_bih) if (g_bih is not None and ctx.has_bias and ctx.needs_input_grad[3]) else None

@@ -231,12 +231,13 @@ def test_gru_backward_with_packed_gate_gradients(dev, m, i, h):
             assert err < 1e-5, (packed, name, err)
 
 
-@pytest.mark.parametrize("m", [6000, 33, 4096 + 17])
+@pytest.mark.parametrize("m", [6000, 33, 4096 + 17, 20_000])
 def test_tracked_whole_table_gru_step(dev, m):
     """The whole-table GRU kernel as a tracked step (gate values kept per state element, the old
     state read from the matrix it came from) against torch.nn.GRUCell in float64: new state and
     the gradients of x, both weights and both biases within 1e-5 of each tensor's largest entry;
-    the state matrix it read is left as it was."""
+    the state matrix it read is left as it was.  At 20000 rows both weight gradients come from
+    one launch (spmi_gemm_tn_pair_sums)."""
     i = h = 128
     w_ih, w_hh, b_ih, b_hh = _params(3, i, h, dev, 21)
     gen = torch.Generator().manual_seed(m)

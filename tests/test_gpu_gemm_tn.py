@@ -143,3 +143,44 @@ def test_whole_block_kernel_at_short_and_ragged_k(dev, k):
         for got, ref in ((sa, big_a[:, 4:]), (sb, big_b[:, :n])):
             err = np.abs(got.cpu().numpy() - ref.astype(np.float64).sum(0))
             assert (err / np.abs(ref).astype(np.float64).sum(0)).max() < 1e-5, (k, m, n)
+
+
+@pytest.mark.parametrize("k", [1, 17, 300, 20_001, 100_000])
+def test_two_products_in_one_launch(dev, k):
+    """spmi_gemm_tn_pair_sums straight through the C-ABI: two products over overlapping column
+    ranges of one [k, 512] matrix (the packed gate gradients of a GRU layer: columns 0..383 with
+    x, columns 128..511 with h), each against float64 at 1e-5 of the sum of absolute terms, with
+    the column sums of both ranges; repeated launches agree bit for bit."""
+    lib = nv.lib()
+    rng = np.random.default_rng(k)
+    g4 = (rng.standard_normal((k, 512)) * 1e-3).astype(np.float32)
+    x = rng.standard_normal((k, 128)).astype(np.float32)
+    h = (rng.standard_normal((k, 128)) * 0.5).astype(np.float32)
+    tg, tx, th = (torch.from_numpy(t).to(dev) for t in (g4, x, h))
+    a0, a1 = tg[:, :384], tg[:, 128:]
+    m, n = 384, 128
+    assert lib.spmi_gemm_tn_pair_supported(m, n) and not lib.spmi_gemm_tn_pair_supported(100, 128)
+    nbytes = lib.spmi_gemm_tn_pair_workspace_bytes(m, n, k)
+
+    def run():
+        c0, c1 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
+        s0, s1 = torch.empty(m, device=dev), torch.empty(m, device=dev)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nv.check(lib.spmi_gemm_tn_pair_sums(
+            nv.ptr(a0), a0.stride(0), nv.ptr(tx), 128, nv.ptr(a1), a1.stride(0), nv.ptr(th), 128, k, m, n,
+            nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), nv.ptr(ws), nbytes, nv.stream()),
+            "spmi_gemm_tn_pair_sums")
+        return c0, c1, s0, s1
+
+    got = run()
+    for a, b, c, s in ((g4[:, :384], x, got[0], got[2]), (g4[:, 128:], h, got[1], got[3])):
+        want = a.astype(np.float64).T @ b.astype(np.float64)
+        scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+        assert (np.abs(c.cpu().numpy() - want) / scale).max() < 1e-5
+        assert (np.abs(s.cpu().numpy() - a.astype(np.float64).sum(0)) / np.abs(a).astype(np.float64).sum(0)).max() < 1e-5
+    again = run()
+    assert all(torch.equal(p, q) for p, q in zip(got, again))
+    if k >= ops.GEMM_TN_MIN_ROWS:
+        assert ops.gemm_tn_pair_ok(a0, tx, a1, th)
+        c0, c1 = ops.gemm_tn_pair(a0, tx, a1, th)
+        assert torch.equal(c0, got[0]) and torch.equal(c1, got[1])
