@@ -324,11 +324,11 @@ int spmi_gru_gate_bwd(const float* gh_out /*[M,H] grad of h_out*/, const float* 
 int spmi_gru_gate_bwd_packed(const float* gh_out /*[M,H]*/, const float* saved /*[M,5H]*/, int64_t M,
                              int64_t H, float* g4 /*[M,4H]*/, float* g_h /*nullable [M,H]*/,
                              void* stream);
-/* The same packed gradients from the gate values spmi_gru_rows_fwd_saved keeps: saved [M, H, 4] =
- * (r, z, n, W_hn h + b_hn) per state element, the old state read from h_old [M, H] (row stride
+/* The same packed gradients from the gate values spmi_gru_rows_fwd_saved keeps: saved [M, 4, H] =
+ * the planes r, z, n, W_hn h + b_hn of every row, the old state read from h_old [M, H] (row stride
  * ldh), the matrix the forward read it from.  H and ldh multiples of 4, pointers 16-byte
  * aligned.  Same autograd step of torch.nn.GRU (implicitTimeModels.py:185-187). */
-int spmi_gru_gate_bwd_packed_q(const float* gh_out /*[M,H]*/, const float* saved /*[M,H,4]*/,
+int spmi_gru_gate_bwd_packed_q(const float* gh_out /*[M,H]*/, const float* saved /*[M,4,H]*/,
                                const float* h_old, int64_t ldh, int64_t M, int64_t H,
                                float* g4 /*[M,4H]*/, void* stream);
 int spmi_lstm_gate_fwd(const float* gi /*[M,4H]*/, const float* gh /*[M,4H]*/,
@@ -431,11 +431,11 @@ int spmi_gru_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t 
                       float* h_out /*device [M, H]*/, int x_bounded, void* stream);
 /* The same step for a caller that will run a backward pass (torch.nn.GRU under autograd in the
  * reference's training loop, examples/torch/citation_prediction.py:96-101): besides h_out it
- * writes saved [M, H, 4] = (r, z, n, W_hn h + b_hn) per state element, the input of
+ * writes saved [M, 4, H] = the planes r, z, n, W_hn h + b_hn of every row, the input of
  * spmi_gru_gate_bwd_packed_q.  saved must overlap none of x, h_in, h_out. */
 int spmi_gru_rows_fwd_saved(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
                             const float* b_ih, const float* b_hh, const float* h_in, int64_t M, int64_t H,
-                            float* h_out, float* saved /*device [M, H, 4]*/, int x_bounded, void* stream);
+                            float* h_out, float* saved /*device [M, 4, H]*/, int x_bounded, void* stream);
 
 /* The tanh RNN layer step on the same loop nest: torch.nn.RNN with seq_len 1 as driven by
  * SequentialDecoder.forward (implicitTimeModels.py:144-158), ids = every node, nothing kept:

@@ -45,7 +45,7 @@ struct GruRowsArgs {
   float* h_out;
   int64_t M;
   int x_bounded;
-  float4* saved;  // SAVE kernels: [M][H] of (r, z, n, W_hn h + b_hn), the gate values a backward pass needs
+  float* saved;  // SAVE kernels: [M][4][H] = r, z, n, W_hn h + b_hn per row, the gate values a backward pass needs
 };
 
 __device__ __forceinline__ float rcpf_(float v) { return __builtin_amdgcn_rcpf(v); }
@@ -114,8 +114,9 @@ __device__ __forceinline__ void kstep_mfma(f32x16 (&acc)[4], const f16x8& p0, co
 
 // KT = I / 16 = H / 16 K-steps per operand; H / 32 column slices.
 // XB: the caller vouches for |x| < 2^15 (no magnitude pass, no scaling code).
-// SAVE: the step is tracked for a backward pass: the gate values of every state element leave
-// as one 16-byte store from the lane that computed them (32 lanes cover 512 contiguous bytes).
+// SAVE: the step is tracked for a backward pass: the gate values of every state element are
+// stored as four [H]-wide planes per row (a store covers two 128-byte row segments, like the
+// stores of the new state), the layout whose lines the backward kernels read whole.
 template <int KT, bool XB, bool SAVE = false>
 __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
   constexpr int H = KT * 16;
@@ -319,10 +320,10 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    float4* sv = nullptr;
+    float* sv = nullptr;
     bool sv_whole = true;
     if constexpr (SAVE) {
-      sv = p.saved + row0 * H + voff;  // element e: + ((e & 3) + 8 (e >> 2)) * H
+      sv = p.saved + row0 * (4 * H) + (4 * lh * 4 * H + j);  // element e: + ((e & 3) + 8 (e >> 2)) * 4 H
       sv_whole = row0 + 32 <= p.M;
     }
 #pragma unroll
@@ -342,7 +343,13 @@ __global__ __launch_bounds__(512, 1) void gru_rows_kernel(GruRowsArgs p) {
       hy[e] = n + z * (hy[e] - n);
       if constexpr (SAVE) {
         const int ur = (e & 3) + 8 * (e >> 2);
-        if (sv_whole || row0 + ur + 4 * lh < p.M) sv[ur * H] = make_float4(r, z, n, hn);
+        if (sv_whole || row0 + ur + 4 * lh < p.M) {
+          float* o = sv + ur * (4 * H);
+          o[0] = r;
+          o[H] = z;
+          o[2 * H] = n;
+          o[3 * H] = hn;
+        }
       }
     }
     prev_row0 = row0;
@@ -711,7 +718,7 @@ static int gru_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_i
   a.x = x; a.ldx = ldx;
   a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
   a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.h_out = h_out; a.M = M; a.x_bounded = x_bounded;
-  a.saved = reinterpret_cast<float4*>(saved);
+  a.saved = saved;
   return launch<8>(a, spmi::as_stream(stream));
 }
 

@@ -188,11 +188,11 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_packed_kernel(const float* _
   if (g_h) st<VEC>(g_h + e.m * H + e.j, dh);
 }
 
-// The same packed gradients from gate values kept per state element, (r, z, n, W_hn h + b_hn) as
-// one float4 (what the whole-table forward of cell_rows.hip writes), and the old state read from
-// the matrix it came from.  A thread handles four consecutive hidden units of one node.
+// The same packed gradients from gate values kept as four planes per row, [M][4][H] = r, z, n,
+// W_hn h + b_hn (what the whole-table forward of cell_rows.hip writes), and the old state read
+// from the matrix it came from.  A thread handles four consecutive hidden units of one node.
 __global__ __launch_bounds__(kThreads) void gru_bwd_packed_q_kernel(const float* __restrict__ g_out,
-                                                                    const float4* __restrict__ saved,
+                                                                    const float* __restrict__ saved,
                                                                     const float* __restrict__ h_old,
                                                                     int64_t ldh, int64_t M, int H,
                                                                     float* __restrict__ g4) {
@@ -200,12 +200,12 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_packed_q_kernel(const float*
   if (!decode<4>(M, H, &e)) return;
   const Pack<4> g = ld<4>(g_out + e.m * H + e.j);
   const Pack<4> h = ld<4>(h_old + e.m * ldh + e.j);
-  const float4* s = saved + e.m * H + e.j;
-  const float4 q[4] = {s[0], s[1], s[2], s[3]};
+  const float* s = saved + e.m * 4 * H + e.j;
+  const Pack<4> rq = ld<4>(s), zq = ld<4>(s + H), nq = ld<4>(s + 2 * H), hq = ld<4>(s + 3 * H);
   Pack<4> dar, daz, dan, danr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {  // the same expressions, in the same order, as gru_bwd_kernel
-    const float r = q[i].x, z = q[i].y, n = q[i].z, hn = q[i].w;
+    const float r = rq.v[i], z = zq.v[i], n = nq.v[i], hn = hq.v[i];
     const float dn = g.v[i] * (1.0f - z);
     const float dz = g.v[i] * (h.v[i] - n);
     dan.v[i] = dn * (1.0f - n * n);
@@ -421,7 +421,7 @@ int spmi_gru_gate_bwd_packed_q(const float* gh_out, const float* saved, const fl
   const int64_t blocks = (work + kThreads - 1) / kThreads;
   SPMI_REQUIRE(blocks < (int64_t{1} << 31), SPMI_ERR_UNSUPPORTED, "spmi_gru_gate_bwd_packed_q: too many elements");
   gru_bwd_packed_q_kernel<<<static_cast<unsigned>(blocks), kThreads, 0, spmi::as_stream(stream)>>>(
-      gh_out, reinterpret_cast<const float4*>(saved), h_old, ldh, M, static_cast<int>(H), g4);
+      gh_out, saved, h_old, ldh, M, static_cast<int>(H), g4);
   SPMI_CHECK_LAUNCH("gru_bwd_packed_q");
   return SPMI_OK;
 }

@@ -1223,7 +1223,7 @@ class GruRowsTracked(torch.autograd.Function):
         if h_in.shape != (m, hd):
             raise nv.SpmiError("gru_rows_tracked: h_in must be the [M, H] state of the rows of x")
         need_grad = _needs_grad(ctx, 5)
-        saved = torch.empty(m, hd, 4, dtype=torch.float32, device=x.device) if need_grad else None
+        saved = torch.empty(m, 4, hd, dtype=torch.float32, device=x.device) if need_grad else None
         h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
         ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
         ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)

@@ -311,3 +311,4 @@ def test_tracked_whole_table_steps_through_the_decoder(dev):
     scale = max(float(g.abs().max()) for g in grads_b.values())
     for k in grads_b:
         assert float((grads_a[k] - grads_b[k]).abs().max()) / scale < 1e-5, k
+
