@@ -19,5 +19,8 @@ for w in config3 config4 config5 small; do
 done
 timeout -k 10 240 python3 bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_train.json 2>> $out/bench.err
 echo "train done"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $out/prof_train -o train --output-format csv -- python3 bench.py --mode train --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_train_profiled.json 2>> $out/prof.err
+python3 scripts/step_timeline.py $(ls $out/prof_train/*kernel_trace.csv | head -1) --marker radix_hist_kernel --every 2 > $out/train_step_timeline.txt
+echo "train profile done"
 scripts/rehearse_bench.sh small > $out/rehearse.txt
 echo "rehearsal done"
