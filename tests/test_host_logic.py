@@ -177,6 +177,38 @@ def test_node_memory_spare_table_and_swap():
     assert moved._spare is None and moved.memory.device.type == "meta"
 
 
+def test_node_memory_adopts_layer_matrices_without_aliasing_the_table():
+    """set_layers(): the state of every node handed over as one matrix per layer (outputs of
+    tracked steps) is read back through layer(k) as it is, and the [L, N, H] table the first
+    reader asks for is a copy of its own: writing the table (update_memory, in-place edits)
+    never reaches the adopted matrices, which an autograd graph may still hold."""
+    import torch
+
+    from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder.implicitTimeModels import NodeMemory
+
+    mem = NodeMemory(5, 3, 2)
+    assert mem.rows() == 5 and mem.layer(1).data_ptr() == mem.memory[1].data_ptr()
+    a = torch.full((5, 3), 1.0, requires_grad=True) * 2.0       # non-leaf, as a step's output is
+    b = torch.full((5, 3), 7.0)
+    mem.set_layers([a, b])
+    assert mem.rows() == 5 and mem.device == a.device
+    assert mem.layer(0).data_ptr() == a.data_ptr() and not mem.layer(0).requires_grad
+    assert mem.layer(1).data_ptr() == b.data_ptr()
+    assert mem.bounded()                                        # boundedness carries over
+    table = mem.memory                                          # first reader: stacked copy
+    assert table.shape == (2, 5, 3) and table.data_ptr() not in (a.data_ptr(), b.data_ptr())
+    assert mem.memory is table and mem.layer(0).data_ptr() == table[0].data_ptr()
+    mem.update_memory(torch.zeros(2, 2, 3), torch.tensor([0, 4]))
+    assert float(a.detach().min()) == 2.0 and float(b.min()) == 7.0   # the adopted matrices are untouched
+    assert mem.memory[:, 0].abs().sum() == 0 and mem.memory[0, 1].eq(2.0).all()
+    mem.set_layers([a, b])
+    mem.memory = torch.ones(2, 5, 3)                            # assignment drops the adopted matrices
+    assert mem.layer(0).eq(1.0).all()
+    mem.set_layers([a, b])
+    moved = mem.to("meta")
+    assert moved.memory.shape == (2, 5, 3) and moved.device.type == "meta"
+
+
 def test_mrr_definition():
     """Reciprocal rank of each positive among its own negatives (the metric the reference takes
     from ogb's Evaluator, examples/tf/link_prediction_sliding_window.py:142-146): hand-computed
