@@ -567,7 +567,12 @@ int spmi_gemm_tn(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/
  * fp32_instruction == 0: products on the bf16 matrix cores at fp32 accuracy: every operand
  * value is split exactly into three bf16 pieces and a product is summed from the six piece
  * products above 2^-24 of its size, fp32 accumulation; no range limit beyond bfloat16's own
- * (fp32's exponent range); 2-3x faster on these shapes (HBM-bound instead of matrix-bound). */
+ * (fp32's exponent range); 2-3x faster on these shapes (HBM-bound instead of matrix-bound).
+ * fp32_instruction == 2: as 0, except that outputs made of whole 128 x 128 blocks (M, N multiples
+ * of 128, M * N <= 512 * 512, aligned operands) are multiplied in three fp16 planes per value
+ * (three products per term, half the matrix work, fp32-chain accuracy) under power-of-two scales
+ * that follow the operands' magnitudes through the rows: the error stays relative to the sum of
+ * absolute terms for operands of any size with |a| |b| within 2^+-100. */
 int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K,N]*/, int64_t ldb,
                       int64_t K, int64_t M, int64_t N, float* C /*[M,N]*/, int64_t ldc,
                       int accumulate, float* col_sum_a /*nullable [M]*/,
@@ -581,13 +586,15 @@ int spmi_gemm_tn_sums(const float* A /*[K,M]*/, int64_t lda, const float* B /*[K
  * whose middle 2H columns both read (3 GB instead of 4 per layer at 1M rows, H = 128).
  * M and N multiples of 128, M * N <= 512 * 512 (spmi_gemm_tn_pair_supported); operands 16-byte
  * aligned, leading dimensions multiples of 4.  Bit-reproducible; the split of K differs from
- * the single product's, so the sums agree with it to fp32 rounding, not bit for bit. */
+ * the single product's, so the sums agree with it to fp32 rounding, not bit for bit.
+ * f16_planes != 0: the arithmetic of spmi_gemm_tn_sums' fp32_instruction == 2. */
 int spmi_gemm_tn_pair_supported(int64_t M, int64_t N);
 size_t spmi_gemm_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int spmi_gemm_tn_pair_sums(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, const float* A1,
                            int64_t lda1, const float* B1, int64_t ldb1, int64_t K, int64_t M, int64_t N,
                            float* C0, int64_t ldc0, float* C1, int64_t ldc1, float* col_sum_a0 /*nullable [M]*/,
-                           float* col_sum_a1 /*nullable [M]*/, void* ws, size_t ws_bytes, void* stream);
+                           float* col_sum_a1 /*nullable [M]*/, int f16_planes, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------
  * Output head in inference, one kernel: the MLP of

@@ -110,7 +110,7 @@ _SIGNATURES = {
     "spmi_gemm_tn_pair_supported": (c_int, [c_i64, c_i64]),
     "spmi_gemm_tn_pair_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "spmi_gemm_tn_pair_sums": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64,
-                                       c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                       c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
     "spmi_mlp_head_supported": (c_int, [c_i64, c_i32, c_i32, c_vp]),
     "spmi_mlp_head_fwd": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp,
                                   c_vp, c_i32, c_vp, c_i64, c_vp]),

@@ -325,6 +325,43 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_partial_x3_kernel(
 //    copy (which would wait for the load) crosses the bottom of the loop.
 //  * The 256 accumulators take the whole accumulation register file: one wave per SIMD.
 using f32x4 = float __attribute__((ext_vector_type(4)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+
+// The fp16 planes of eight values (already scaled into fp16's range), as the bit patterns the
+// kernel keeps its bf16 pieces in: p0 = fp16(v), p1 = p0 / 64, p2 = fp16((v - p0) * 64).
+__device__ __forceinline__ void split_planes8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+  f16x8 a, c;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = static_cast<_Float16>(v[i]);
+  const f16x8 b = a * static_cast<_Float16>(0x1p-6f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float d = __builtin_fmaf(static_cast<float>(a[i]), -1.0f, v[i]);
+    c[i] = static_cast<_Float16>(d * 0x1p6f);
+  }
+  p0 = __builtin_bit_cast(bf16x8, a);
+  p1 = __builtin_bit_cast(bf16x8, b);
+  p2 = __builtin_bit_cast(bf16x8, c);
+}
+
+// Largest of the lanes' non-negative floats, as a wave-uniform bit pattern.  Row shifts and row
+// broadcasts of the data-parallel primitives (no LDS crossbar): lane 63 ends up with the maximum.
+__device__ __forceinline__ uint32_t wave_max_bits(float v) {
+  int x = static_cast<int>(__float_as_uint(v));  // non-negative floats order like their bit patterns
+#define SPMI_DPP_MAX(ctrl, row_mask)                                                        \
+  {                                                                                         \
+    const int o = __builtin_amdgcn_update_dpp(x, x, ctrl, row_mask, 0xf, false);            \
+    x = o > x ? o : x;                                                                      \
+  }
+  SPMI_DPP_MAX(0x111, 0xf)  // row_shr:1
+  SPMI_DPP_MAX(0x112, 0xf)  // row_shr:2
+  SPMI_DPP_MAX(0x114, 0xf)  // row_shr:4
+  SPMI_DPP_MAX(0x118, 0xf)  // row_shr:8: lane 15 of every row holds the row's maximum
+  SPMI_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  SPMI_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef SPMI_DPP_MAX
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(x, 63));
+}
 
 // One launch may carry a second product of the same shape over the same rows (`second`): the
 // waves of one chunk of K then run side by side for both, so that columns the two products
@@ -340,6 +377,23 @@ struct TnProblem {
   float* sum_b_partial;
 };
 
+//
+// F16 = false: three exact bf16 pieces per value, six piece products per term (no range limit).
+// F16 = true: the fp16 planes of cell_split.hip (p0 = fp16(v), p1 = p0 / 64, p2 = fp16((v - p0)
+// * 64); x * w = p0 p0 + p1 p2 + p2 p1), three products per term: half the matrix work, which is
+// what bounds this kernel (1.18 TFLOP of piece products per GRU layer at 1M rows against 3 GB).
+// fp16 has 30 binades and gradients of a mean loss over a million rows sit 20 below 1, so the
+// operands are scaled by powers of two on the way: every K-step (16 rows) the wave takes the
+// largest exponents eA, eB of its two operand tiles.  The first step that is not all zeros fixes
+// the exponent S that every product of the wave's chunk carries (taken out when the partial
+// block is written): S = 14 - eA - eB, the middle of the range.  Every step then scales A by
+// 2^(pA - eA) and B by 2^(pB - eB) with pA + pB = eA + eB + S split evenly, which fits fp16 as
+// long as the step's operands are no more than 2^14 times larger than those S was set by; at a
+// step beyond that the wave adds what it has to its partial block under the old S, starts again
+// from zero and sets S by that step (rare, wave-uniform).  Steps far smaller than the one that set S lose relative, not
+// absolute accuracy (the residual plane keeps what plane 0 drops): the error stays relative to
+// the sum of absolute terms.  Domain: |a| |b| within 2^+-100.
+template <bool F16>
 __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
     TnProblem first, TnProblem second, int n_problems, int64_t K, int M, int N, int64_t k_chunk,
     int n_chunks) {
@@ -365,13 +419,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
   const uint32_t a_off = static_cast<uint32_t>(lh * 8 * lda + m0 + 4 * lr);
   const uint32_t b_off = static_cast<uint32_t>(lh * 8 * ldb + n0 + 4 * lr);
 
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.0f;
+  f32x16 acc[4][4];  // zeroed at the top of every pass over the chunk, written out at its end
   const bool want_sa = sum_a_partial != nullptr && n0 == 0;
   const bool want_sb = sum_b_partial != nullptr && m0 == 0;
   f32x4 sa = {}, sb = {};
@@ -390,7 +438,37 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
       bv[u] = *reinterpret_cast<const f32x4*>(B + row * ldb + b_off);
     }
   };
-  bf16x8 ah[4], am[4], al[4], bh[4], bm[4], bl[4];
+  // element e of lane l in tile (s, t): row index (e&3) + 8 (e>>2) + 4 lh and column index lr
+  // of the instruction grid, i.e. C[m0 + 4 * row index + s][n0 + 4 lr + t].  `exponent`: the
+  // power of two the accumulators carry (F16; taken out here, in two factors so that neither
+  // leaves fp32's range); `add`: the block already holds an earlier part of the chunk's sum.
+  float* out = partial + static_cast<size_t>(chunk) * M * N;
+  auto write_partial = [&](int exponent, bool add) {
+    const int h1 = exponent / 2, h2 = exponent - h1;
+    const float u1 = __uint_as_float(static_cast<uint32_t>(127 - h1) << 23);
+    const float u2 = __uint_as_float(static_cast<uint32_t>(127 - h2) << 23);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * lh) + s;
+        f32x4 v = {acc[s][0][e], acc[s][1][e], acc[s][2][e], acc[s][3][e]};
+        f32x4* dst = reinterpret_cast<f32x4*>(out + static_cast<size_t>(m) * N + n0 + 4 * lr);
+        if constexpr (F16) v = v * u1 * u2;
+        if (add) v += *dst;
+        *dst = v;
+      }
+  };
+  // F16: passes over the chunk.  A pass takes the steps whose exponent sum eA + eB lies above
+  // `done_below` (what earlier passes took) and fits under the pass's S; the largest sum among
+  // the steps it had to leave sets the S of the next pass.  One pass unless a chunk's operands
+  // grow 2^14-fold after its first rows.
+  int done_below = -(1 << 20), deferred_max = -(1 << 20);
+  bool flushed = false;  // the partial block already holds the sums of earlier passes
+  bool first_pass = true;  // the operand column sums are taken once
+  bf16x8 ah[4], am[4], al[4], bh[4], bm[4], bl[4];  // F16: planes 0, 1, 2 as bit patterns
+  constexpr int kNoScale = 1 << 20;
+  int run_s = kNoScale;  // F16: the exponent S every product of the chunk carries (set by its first non-zero step)
   auto split_all = [&](auto full_tag, int64_t k, f32x4 (&av)[8], f32x4 (&bv)[8]) {
     constexpr bool FULL = decltype(full_tag)::value;
     if constexpr (!FULL) {
@@ -401,21 +479,66 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
           bv[u] = f32x4{};
         }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      sa += av[u];
-      sb += bv[u];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[8], w8[8];
+    if (first_pass) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        v[u] = av[u][j];
-        w8[u] = bv[u][j];
+        sa += av[u];
+        sb += bv[u];
       }
-      split3x8(v, ah[j], am[j], al[j]);
-      split3x8(w8, bh[j], bm[j], bl[j]);
+    }
+    if constexpr (F16) {
+      // largest magnitudes of the two operand tiles of this K-step (NaN is ignored by the maximum
+      // and multiplied like any other value)
+      float fa_max = 0.0f, fb_max = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        fa_max = fmaxf(fmaxf(fa_max, fmaxf(fabsf(av[u][0]), fabsf(av[u][1]))), fmaxf(fabsf(av[u][2]), fabsf(av[u][3])));
+        fb_max = fmaxf(fmaxf(fb_max, fmaxf(fabsf(bv[u][0]), fabsf(bv[u][1]))), fmaxf(fabsf(bv[u][2]), fabsf(bv[u][3])));
+      }
+      const uint32_t ma = wave_max_bits(fa_max), mb = wave_max_bits(fb_max);
+      // A tile of zeros adds nothing, a step that an earlier pass over the chunk has taken is
+      // done, and a step whose operands do not fit under this pass's S waits for the next pass:
+      // in all three cases both operands are multiplied by zero (no branch around the matrix
+      // instructions; the other tile, unscaled, could leave fp16's range).
+      int ea = static_cast<int>(ma >> 23) - 127, eb = static_cast<int>(mb >> 23) - 127;
+      ea = ea > 100 ? 100 : (ea < -100 ? -100 : ea);
+      eb = eb > 100 ? 100 : (eb < -100 ? -100 : eb);
+      bool live = ma != 0 && mb != 0 && ea + eb > done_below;
+      if (live && run_s == kNoScale) run_s = 14 - ea - eb;  // the pass's first products land mid-range
+      if (live && ea + eb + run_s > 28) {
+        live = false;
+        deferred_max = ea + eb > deferred_max ? ea + eb : deferred_max;
+      }
+      const int total = ea + eb + (run_s == kNoScale ? 0 : run_s);
+      int pa = total >> 1;
+      pa = pa < -100 ? -100 : pa;
+      int xb2 = total - pa - eb;
+      xb2 = xb2 > 126 ? 126 : (xb2 < -126 ? -126 : xb2);
+      const float fa = live ? __uint_as_float(static_cast<uint32_t>(127 + pa - ea) << 23) : 0.0f;
+      const float fb = live ? __uint_as_float(static_cast<uint32_t>(127 + xb2) << 23) : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8], w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = av[u][j] * fa;
+          w8[u] = bv[u][j] * fb;
+        }
+        split_planes8(v, ah[j], am[j], al[j]);
+        split_planes8(w8, bh[j], bm[j], bl[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[8], w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = av[u][j];
+          w8[u] = bv[u][j];
+        }
+        split3x8(v, ah[j], am[j], al[j]);
+        split3x8(w8, bh[j], bm[j], bl[j]);
+      }
     }
   };
   auto multiply = [&]() {
@@ -423,47 +546,73 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {  // smallest terms first
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bm[t], acc[s][t], 0, 0, 0);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[t], acc[s][t], 0, 0, 0);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[t], acc[s][t], 0, 0, 0);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bh[t], acc[s][t], 0, 0, 0);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bm[t], acc[s][t], 0, 0, 0);
-        acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[t], acc[s][t], 0, 0, 0);
+        if constexpr (F16) {
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[s]),
+                                                             __builtin_bit_cast(f16x8, bm[t]), acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, am[s]),
+                                                             __builtin_bit_cast(f16x8, bl[t]), acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[s]),
+                                                             __builtin_bit_cast(f16x8, bh[t]), acc[s][t], 0, 0, 0);
+        } else {
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bm[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], bh[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bm[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[t], acc[s][t], 0, 0, 0);
+        }
       }
   };
 
   // k_chunk is a multiple of 16, so only the last chunk of K can end in a partial step
   f32x4 a[8], b[8], a2[8], b2[8];
-  const int64_t n_full = (k_end - k_begin) / 16;
-  int64_t k = k_begin;
-  if (n_full > 0) load(std::true_type{}, k, a, b);
-  int64_t i = 0;
-  for (; i + 2 <= n_full; i += 2, k += 32) {
-    // two steps per trip, two sets of load registers: a step's loads are issued a whole step
-    // ahead.  No branch around the loads (the wait counts stay exact): the last trip re-reads
-    // its own rows.
-    load(std::true_type{}, k + 16, a2, b2);
-    __builtin_amdgcn_sched_barrier(0);
-    split_all(std::true_type{}, k, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply();
-    __builtin_amdgcn_sched_barrier(0);
-    load(std::true_type{}, i + 2 < n_full ? k + 32 : k, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    split_all(std::true_type{}, k + 16, a2, b2);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (i < n_full) {
-    split_all(std::true_type{}, k, a, b);
-    multiply();
-    k += 16;
-  }
-  if (k < k_end) {
-    load(std::false_type{}, k, a, b);
-    split_all(std::false_type{}, k, a, b);
-    multiply();
+  for (;;) {  // one trip unless F16 has to come back for steps it left (see done_below)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][t][e] = 0.0f;
+    const int64_t n_full = (k_end - k_begin) / 16;
+    int64_t k = k_begin;
+    if (n_full > 0) load(std::true_type{}, k, a, b);
+    int64_t i = 0;
+    for (; i + 2 <= n_full; i += 2, k += 32) {
+      // two steps per trip, two sets of load registers: a step's loads are issued a whole step
+      // ahead.  No branch around the loads (the wait counts stay exact): the last trip re-reads
+      // its own rows.
+      load(std::true_type{}, k + 16, a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      split_all(std::true_type{}, k, a, b);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply();
+      __builtin_amdgcn_sched_barrier(0);
+      load(std::true_type{}, i + 2 < n_full ? k + 32 : k, a, b);
+      __builtin_amdgcn_sched_barrier(0);
+      split_all(std::true_type{}, k + 16, a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < n_full) {
+      split_all(std::true_type{}, k, a, b);
+      multiply();
+      k += 16;
+    }
+    if (k < k_end) {
+      load(std::false_type{}, k, a, b);
+      split_all(std::false_type{}, k, a, b);
+      multiply();
+    }
+    // what this pass summed goes to the partial block (on top of earlier passes' sums)
+    write_partial(F16 && run_s != kNoScale ? run_s : 0, flushed);
+    if (!F16 || deferred_max == -(1 << 20)) break;
+    // the next pass takes the steps this one had to leave
+    flushed = true;
+    first_pass = false;
+    done_below = 28 - run_s;
+    run_s = 14 - deferred_max;
+    deferred_max = -(1 << 20);
   }
 
   if (want_sa) {  // rows k + 0..7 and k + 8..15 of every step sit in the two lane halves
@@ -478,17 +627,6 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
     for (int c = 0; c < 4; ++c) v[c] = sb[c] + __shfl_xor(sb[c], 32);
     if (lh == 0) *reinterpret_cast<f32x4*>(sum_b_partial + static_cast<size_t>(chunk) * N + n0 + 4 * lr) = v;
   }
-  // element e of lane l in tile (s, t): row index (e&3) + 8 (e>>2) + 4 lh and column index lr
-  // of the instruction grid, i.e. C[m0 + 4 * row index + s][n0 + 4 lr + t]
-  float* out = partial + static_cast<size_t>(chunk) * M * N;
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * lh) + s;
-      const f32x4 v = {acc[s][0][e], acc[s][1][e], acc[s][2][e], acc[s][3][e]};
-      *reinterpret_cast<f32x4*>(out + static_cast<size_t>(m) * N + n0 + 4 * lr) = v;
-    }
 }
 
 // C = (accumulate ? C : 0) + sum over chunks.  L lanes share one output element: lane c of
@@ -642,7 +780,7 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
   SPMI_REQUIRE(ws_bytes >= spmi_gemm_tn_workspace_bytes(M, N, K), SPMI_ERR_WORKSPACE,
                "spmi_gemm_tn: workspace %zu < required %zu", ws_bytes,
                spmi_gemm_tn_workspace_bytes(M, N, K));
-  const bool pieces = fp32_instruction == 0;
+  const bool pieces = fp32_instruction != 1;
   const bool wide = pieces && wide_shape(M, N) && lda % 4 == 0 && ldb % 4 == 0 &&
                     ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15u) == 0;
   const Shape s = wide ? plan_wide(M, N, K) : plan(M, N, K, pieces);
@@ -663,8 +801,12 @@ int spmi_gemm_tn_sums(const float* A, int64_t lda, const float* B, int64_t ldb, 
   if (wide) {
     const unsigned wgs = static_cast<unsigned>((s.m_strips * s.n_tiles * s.n_chunks + kWaves - 1) / kWaves);
     const TnProblem one{A, lda, B, ldb, partial, pa, pb};
-    gemm_tn_partial_x3_wide_kernel<<<wgs, kThreads, 0, st>>>(one, one, 1, K, (int)M, (int)N, s.k_chunk,
-                                                             s.n_chunks);
+    if (fp32_instruction == 2)
+      gemm_tn_partial_x3_wide_kernel<true><<<wgs, kThreads, 0, st>>>(one, one, 1, K, (int)M, (int)N, s.k_chunk,
+                                                                     s.n_chunks);
+    else
+      gemm_tn_partial_x3_wide_kernel<false><<<wgs, kThreads, 0, st>>>(one, one, 1, K, (int)M, (int)N, s.k_chunk,
+                                                                      s.n_chunks);
   } else if (pieces) {
     if (s.mt == 2 && s.nt == 2) SPMI_GEMM_TN_X3(2, 2);
     else if (s.mt == 2) SPMI_GEMM_TN_X3(2, 1);
@@ -690,7 +832,7 @@ size_t spmi_gemm_tn_pair_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 int spmi_gemm_tn_pair_sums(const float* A0, int64_t lda0, const float* B0, int64_t ldb0, const float* A1,
                            int64_t lda1, const float* B1, int64_t ldb1, int64_t K, int64_t M, int64_t N,
                            float* C0, int64_t ldc0, float* C1, int64_t ldc1, float* col_sum_a0,
-                           float* col_sum_a1, void* ws, size_t ws_bytes, void* stream) {
+                           float* col_sum_a1, int f16_planes, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_gemm_tn(M, N, K)) return rc;
   SPMI_REQUIRE(wide_shape(M, N), SPMI_ERR_UNSUPPORTED,
                "spmi_gemm_tn_pair_sums: M and N must be multiples of 128 with M*N <= 512*512 (M=%lld N=%lld)",
@@ -720,8 +862,13 @@ int spmi_gemm_tn_pair_sums(const float* A0, int64_t lda0, const float* B0, int64
   const TnProblem first{A0, lda0, B0, ldb0, p0, sa0, nullptr};
   const TnProblem second{A1, lda1, B1, ldb1, p1, sa1, nullptr};
   const int64_t waves = static_cast<int64_t>(s.m_strips) * s.n_tiles * 2 * s.n_chunks;
-  gemm_tn_partial_x3_wide_kernel<<<static_cast<unsigned>((waves + kWaves - 1) / kWaves), kThreads, 0, st>>>(
-      first, second, 2, K, (int)M, (int)N, s.k_chunk, s.n_chunks);
+  const unsigned wgs = static_cast<unsigned>((waves + kWaves - 1) / kWaves);
+  if (f16_planes)
+    gemm_tn_partial_x3_wide_kernel<true><<<wgs, kThreads, 0, st>>>(first, second, 2, K, (int)M, (int)N, s.k_chunk,
+                                                                   s.n_chunks);
+  else
+    gemm_tn_partial_x3_wide_kernel<false><<<wgs, kThreads, 0, st>>>(first, second, 2, K, (int)M, (int)N, s.k_chunk,
+                                                                    s.n_chunks);
   SPMI_CHECK_LAUNCH("gemm_tn_partial(pair)");
   if (int rc = reduce_chunks(p0, sa0, nullptr, s.n_chunks, M, N, C0, ldc0, 0, col_sum_a0, nullptr, st)) return rc;
   return reduce_chunks(p1, sa1, nullptr, s.n_chunks, M, N, C1, ldc1, 0, col_sum_a1, nullptr, st);

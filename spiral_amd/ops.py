@@ -103,6 +103,9 @@ GEMM_TN_MIN_ROWS = 16384  # below this many rows the library GEMM is as good
 # products per term on the bf16 matrix cores (fp32-accurate, no range limit, 2-3x faster);
 # "fp32" = the fp32 matrix instruction.
 GEMM_TN_MODE = "bf16x3"
+# Outputs made of whole 128 x 128 blocks (the layer and gate weights of the path) in three fp16
+# planes per value under running power-of-two scales: three products per term instead of six.
+GEMM_TN_F16_BLOCKS = True
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, sum_a: bool = False, sum_b: bool = False):
@@ -128,7 +131,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, sum_a: bool = False, sum_b: bool =
         ws_bytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         nv.check(lib.spmi_gemm_tn_sums(nv.ptr(a), a.stride(0), nv.ptr(b), b.stride(0), k, m, n,
-                                       nv.ptr(out), n, 0, nv.ptr(sa), nv.ptr(sb), int(GEMM_TN_MODE == "fp32"),
+                                       nv.ptr(out), n, 0, nv.ptr(sa), nv.ptr(sb),
+                                       1 if GEMM_TN_MODE == "fp32" else (2 if GEMM_TN_F16_BLOCKS else 0),
                                        nv.ptr(ws), ws_bytes, nv.stream()), "spmi_gemm_tn_sums")
     return (out, sa, sb) if sums else out
 
@@ -175,8 +179,8 @@ def gemm_tn_pair(a0: torch.Tensor, b0: torch.Tensor, a1: torch.Tensor, b1: torch
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a0.device)
         nv.check(lib.spmi_gemm_tn_pair_sums(
             nv.ptr(a0), a0.stride(0), nv.ptr(b0), b0.stride(0), nv.ptr(a1), a1.stride(0), nv.ptr(b1),
-            b1.stride(0), k, m, n, nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), nv.ptr(ws), ws_bytes,
-            nv.stream()), "spmi_gemm_tn_pair_sums")
+            b1.stride(0), k, m, n, nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), int(GEMM_TN_F16_BLOCKS),
+            nv.ptr(ws), ws_bytes, nv.stream()), "spmi_gemm_tn_pair_sums")
     return (c0, c1, s0, s1) if sums else (c0, c1)
 
 

@@ -162,25 +162,71 @@ def test_two_products_in_one_launch(dev, k):
     assert lib.spmi_gemm_tn_pair_supported(m, n) and not lib.spmi_gemm_tn_pair_supported(100, 128)
     nbytes = lib.spmi_gemm_tn_pair_workspace_bytes(m, n, k)
 
-    def run():
+    def run(f16_planes=1):
         c0, c1 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
         s0, s1 = torch.empty(m, device=dev), torch.empty(m, device=dev)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         nv.check(lib.spmi_gemm_tn_pair_sums(
             nv.ptr(a0), a0.stride(0), nv.ptr(tx), 128, nv.ptr(a1), a1.stride(0), nv.ptr(th), 128, k, m, n,
-            nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), nv.ptr(ws), nbytes, nv.stream()),
+            nv.ptr(c0), n, nv.ptr(c1), n, nv.ptr(s0), nv.ptr(s1), f16_planes, nv.ptr(ws), nbytes, nv.stream()),
             "spmi_gemm_tn_pair_sums")
         return c0, c1, s0, s1
 
-    got = run()
-    for a, b, c, s in ((g4[:, :384], x, got[0], got[2]), (g4[:, 128:], h, got[1], got[3])):
-        want = a.astype(np.float64).T @ b.astype(np.float64)
-        scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
-        assert (np.abs(c.cpu().numpy() - want) / scale).max() < 1e-5
-        assert (np.abs(s.cpu().numpy() - a.astype(np.float64).sum(0)) / np.abs(a).astype(np.float64).sum(0)).max() < 1e-5
+    for planes in (0, 1):  # bf16 pieces, fp16 planes under running scales
+        got = run(planes)
+        for a, b, c, s in ((g4[:, :384], x, got[0], got[2]), (g4[:, 128:], h, got[1], got[3])):
+            want = a.astype(np.float64).T @ b.astype(np.float64)
+            scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+            assert (np.abs(c.cpu().numpy() - want) / scale).max() < 1e-5, planes
+            assert (np.abs(s.cpu().numpy() - a.astype(np.float64).sum(0)) / np.abs(a).astype(np.float64).sum(0)).max() < 1e-5
     again = run()
     assert all(torch.equal(p, q) for p, q in zip(got, again))
     if k >= ops.GEMM_TN_MIN_ROWS:
         assert ops.gemm_tn_pair_ok(a0, tx, a1, th)
         c0, c1 = ops.gemm_tn_pair(a0, tx, a1, th)
         assert torch.equal(c0, got[0]) and torch.equal(c1, got[1])
+
+
+@pytest.mark.parametrize("case", ["wild_rows", "tiny_then_large", "zero_tiles", "gradient_sized", "large"])
+def test_whole_block_fp16_planes_follow_the_operands_magnitudes(dev, case):
+    """The fp16-plane arithmetic of the whole-block kernel (fp32_instruction = 2) scales its
+    operands K-step by K-step: rows whose magnitudes differ by 2^50 inside one chunk, a chunk that
+    starts 2^40 below where it ends (a second pass over the chunk takes the steps that did not fit),
+    tiles of zeros, gradients of 1e-7 against activations of 1e3, values of 1e8; each against
+    float64 at 1e-5 of the sum of absolute terms, with the bf16-piece arithmetic beside it."""
+    lib = nv.lib()
+    k, m, n = 40_000, 128, 256
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((k, m))
+    b = rng.standard_normal((k, n))
+    if case == "wild_rows":
+        a *= np.exp(rng.uniform(-30, 5, (k, 1)))
+        b *= np.exp(rng.uniform(-5, 5, (k, 1)))
+    elif case == "tiny_then_large":
+        ramp = np.where(np.arange(k) % 8000 < 48, 2.0 ** -40, 1.0)[:, None]   # every chunk region starts tiny
+        a *= ramp
+    elif case == "zero_tiles":
+        a[: k // 2 : 1][(np.arange(k // 2) // 16) % 3 == 0] = 0.0
+        b[(np.arange(k) // 16) % 5 == 1] = 0.0
+    elif case == "gradient_sized":
+        a *= 1e-7
+        b *= 1e3
+    else:
+        a *= 1e8
+        b *= 1e8
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    at, bt = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64)
+    nbytes = lib.spmi_gemm_tn_workspace_bytes(m, n, k)
+    errs = {}
+    for mode in (0, 2):
+        c = torch.empty(m, n, device=dev)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        nv.check(lib.spmi_gemm_tn_sums(nv.ptr(at), m, nv.ptr(bt), n, k, m, n, nv.ptr(c), n, 0, None, None, mode,
+                                       nv.ptr(ws), nbytes, nv.stream()), "spmi_gemm_tn_sums")
+        got = c.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), (case, mode)
+        errs[mode] = float((np.abs(got - want) / np.maximum(scale, 1e-300)).max())
+    print(case, "bf16 pieces", errs[0], "fp16 planes", errs[2])
+    assert errs[0] < 1e-5 and errs[2] < 1e-5, (case, errs)
