@@ -370,6 +370,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: 'weak' multiplies the workload's nodes and edges by N, 'strong' splits "
                          "the workload as it is over the N ranks")
+    ap.add_argument("--tie-order", default="multiply_first", choices=["multiply_first", "aggregate_first"],
+                    help="GraphConv layers with in_feats == out_feats: 'multiply_first' (X W, then the "
+                         "aggregation; the default of this package) or 'aggregate_first' (DGL's order on a tie)")
     ap.add_argument("--exchange", default="pipelined", choices=["pipelined", "plain"],
                     help="N>1, forward: 'pipelined' aggregates the replicated input of layer 1 on every "
                          "rank (no exchange) and overlaps the layer-2 exchange of snapshot t with the "
@@ -473,6 +476,9 @@ def main():
     if kind != "gcn_gru" and multi:
         raise SystemExit(f"workload {args.workload} is single-GPU in this bench")
     model = Path(f, w["hidden"], w["rnn_hidden"], n_local, dev, kind)
+    for conv in (getattr(model, "conv1", None), getattr(model, "conv2", None)):
+        if conv is not None and hasattr(conv, "tie_order"):
+            conv.tie_order = args.tie_order
     if kind == "evolve_bf16":
         x_local = x_local.to(torch.bfloat16)
     ids = identity_ids(n_local, dev)
@@ -807,9 +813,12 @@ def main():
                        "step": ("COO->CSR+norm, weight GRU x2, 2x GraphConv (bf16 rows), "
                                 if kind == "evolve_bf16" else
                                 f"COO->CSR+norm, 2x GraphConv({f}->{w['hidden']}, leaky_relu"
-                                + (": X W first, then the aggregation; on this in = out tie DGL "
-                                   "aggregates first -- same result within 1e-5, tested against the "
-                                   "DGL-order oracle" if f == w['hidden'] else "") + "), "
+                                + ((": X W first, then the aggregation; on this in = out tie DGL "
+                                    "aggregates first -- same result within 1e-5, tested against the "
+                                    "DGL-order oracle; --tie-order aggregate_first times DGL's order"
+                                    if args.tie_order == "multiply_first" else
+                                    ": the aggregation first, then X W (DGL's order on this in = out tie)")
+                                   if f == w['hidden'] else "") + "), "
                                 f"2-layer GRU({w['rnn_hidden']}) + MLP, ")
                                + ("forward + MSE + backward + Adam" if train else "forward"),
                        "head": "one-kernel inference MLP" if MLP.FUSE_EVAL and not train else "torch layers",

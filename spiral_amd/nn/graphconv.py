@@ -49,6 +49,11 @@ class GraphConv(WeightCacheHooks, nn.Module):
                 f'Invalid norm value. Must be either "none", "both", "right" or "left". But got "{norm}".')
         self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
         self._allow_zero_in_degree = allow_zero_in_degree
+        # in_feats == out_feats: both orders give the same result.  DGL aggregates first on a tie
+        # (dgl/nn/pytorch/conv/graphconv.py: `if self._in_feats > self._out_feats` multiplies first);
+        # here the tie multiplies first by default, because the projection's output then feeds the
+        # aggregation's fused epilogue.  "aggregate_first" takes DGL's order.
+        self.tie_order = "multiply_first"
         if weight:
             self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
         else:
@@ -89,15 +94,19 @@ class GraphConv(WeightCacheHooks, nn.Module):
             weight = self.weight
 
         code, slope, unfused = _classify_activation(self._activation)
+        if self.tie_order not in ("multiply_first", "aggregate_first"):
+            raise GraphError(f'tie_order must be "multiply_first" or "aggregate_first", got "{self.tie_order}"')
+        mult_first = self._in_feats > self._out_feats or (
+            self._in_feats == self._out_feats and self.tie_order == "multiply_first")
 
         tracked = torch.is_grad_enabled() and (feat.requires_grad or (weight is not None and weight.requires_grad)
                                                or (self.bias is not None and self.bias.requires_grad))
         rst = None
-        if (self._in_feats >= self._out_feats and weight is not None and edge_weight is None and not tracked
+        if (mult_first and weight is not None and edge_weight is None and not tracked
                 and feat.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32):
             # bfloat16 rows against the float32 weight: spmi_gemm_rows_bf16 keeps the weight's value
             rst = graphconv_inference(graph, feat, weight, self._norm, self.bias, code, slope)
-        elif (self._in_feats >= self._out_feats and weight is not None and edge_weight is None and tracked
+        elif (mult_first and weight is not None and edge_weight is None and tracked
               and feat.dtype == torch.float32 and weight.dtype == torch.float32):
             # the same kernels under autograd (no per-edge weight in either direction)
             rst = graphconv_project_first(graph, feat, weight, self._norm, self.bias, code, slope)
@@ -105,7 +114,7 @@ class GraphConv(WeightCacheHooks, nn.Module):
             weight = weight.to(feat.dtype)  # bf16 feature storage on the library path: the projection runs in bf16
         if rst is not None:
             pass
-        elif self._in_feats >= self._out_feats:
+        elif mult_first:
             if weight is not None:
                 feat = rows_times_weight(feat, weight)
             rst = gcn_aggregate(graph, feat, self._norm, self.bias, edge_weight, code, slope)

@@ -240,3 +240,39 @@ def test_tracked_layer_on_the_inference_kernels(dev, norm, fi, fo, act):
     conv.zero_grad()
     (conv(graph, xg.detach()) ** 2).mean().backward()
     assert rel(conv.weight.grad.cpu(), wt.grad) < 1e-5 and rel(conv.bias.grad.cpu(), bt.grad) < 1e-5
+
+
+@pytest.mark.parametrize("norm", ["both", "right"])
+@pytest.mark.parametrize("tracked", [False, True])
+def test_tie_order_takes_dgls_order_on_request(dev, norm, tracked):
+    """in_feats == out_feats: `tie_order = "aggregate_first"` runs DGL's order on the tie (the
+    aggregation, then X W), the default multiplies first; both against the oracle's
+    GraphConv.forward (DGL's order of operations) at 1e-5 of the largest output, with and without
+    autograd, and the gradients of the two orders against each other."""
+    n, e, f = 6000, 60_000, 128
+    rng = np.random.default_rng(5)
+    src, dst = orc.powerlaw_snapshot(n, e, t=3)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    w = (rng.standard_normal((f, f)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(f).astype(np.float32)
+    want = orc.graphconv_forward(src, dst, n, x, w, b, norm=norm, act="leaky_relu", allow_zero_in_degree=True)
+    graph = SnapshotGraph(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+    grads = {}
+    for order in ("multiply_first", "aggregate_first"):
+        conv = _layer(f, f, w, b, dev, norm=norm, activation=F.leaky_relu)
+        conv.tie_order = order
+        xt = torch.from_numpy(x).to(dev)
+        if tracked:
+            got = conv(graph, xt)
+            got.pow(2).mean().backward()
+            grads[order] = (conv.weight.grad.clone(), conv.bias.grad.clone())
+        else:
+            with torch.no_grad():
+                got = conv(graph, xt)
+        assert rel(got.detach().cpu(), want) < 1e-5, (order, norm, tracked)
+    if tracked:
+        for a, c in zip(grads["multiply_first"], grads["aggregate_first"]):
+            assert rel(a.cpu(), c.cpu()) < 1e-5
+    conv.tie_order = "sideways"
+    with pytest.raises(Exception):
+        conv(graph, torch.from_numpy(x).to(dev))
