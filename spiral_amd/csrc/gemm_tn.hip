@@ -330,21 +330,50 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_partial_x3_kernel(
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
 
-// The fp16 planes of eight values (already scaled into fp16's range), as the bit patterns the
-// kernel keeps its bf16 pieces in: p0 = fp16(v), p1 = p0 / 64, p2 = fp16((v - p0) * 64).
-__device__ __forceinline__ void split_planes8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-  f16x8 a, c;
+// The fp16 planes of an operand tile as a lane holds it (eight rows of four columns), times a
+// power of two f that brings it into fp16's range, as the bit patterns the kernel keeps its
+// bf16 pieces in: p0 = fp16(v), p1 = p0 / 64, p2 = fp16((v - p0) * 64); plane register j holds
+// column j of the eight rows.  The scaling runs as packed multiplies over the registers as
+// they were loaded (column pairs are neighbours there), in place, first by f for p0 and then
+// by 64 for the residual, which comes from one mixed-precision fused multiply-add per value:
+// fp16(p0 * -64 + 64 v), the fp16 operand read as it is, one rounding.  64 v is exact and
+// v - p0 has at most 13 significant bits, so the value is that of widening p0, subtracting,
+// scaling and narrowing.  Six vector instructions per two values.
+__device__ __forceinline__ void split_tile(f32x4 (&t)[8], float f, bf16x8 (&p0)[4], bf16x8 (&p1)[4],
+                                           bf16x8 (&p2)[4]) {
+  using f16x2 = _Float16 __attribute__((ext_vector_type(2)));
+  uint32_t a[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = static_cast<_Float16>(v[i]);
-  const f16x8 b = a * static_cast<_Float16>(0x1p-6f);
+  for (int u = 0; u < 8; ++u) t[u] *= f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float d = __builtin_fmaf(static_cast<float>(a[i]), -1.0f, v[i]);
-    c[i] = static_cast<_Float16>(d * 0x1p6f);
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a[j][i]) : "v"(t[2 * i][j]), "v"(t[2 * i + 1][j]));
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t[u] *= 64.0f;
+  const float m64 = -64.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      b[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a[j][i]) * static_cast<_Float16>(0x1p-6f));
+      // the low half first: the register's other half is whatever it held and is written next
+      asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(c[i]) : "v"(a[j][i]), "v"(m64), "v"(t[2 * i][j]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(c[i]) : "v"(a[j][i]), "v"(m64), "v"(t[2 * i + 1][j]));
+    }
+    p0[j] = __builtin_bit_cast(bf16x8, (uint4{a[j][0], a[j][1], a[j][2], a[j][3]}));
+    p1[j] = __builtin_bit_cast(bf16x8, (uint4{b[0], b[1], b[2], b[3]}));
+    p2[j] = __builtin_bit_cast(bf16x8, (uint4{c[0], c[1], c[2], c[3]}));
   }
-  p0 = __builtin_bit_cast(bf16x8, a);
-  p1 = __builtin_bit_cast(bf16x8, b);
-  p2 = __builtin_bit_cast(bf16x8, c);
+}
+
+// max(m, |x|, |y|) in one instruction (the compiler's fmaxf chain spends one more per value on
+// quieting signalling NaNs).  NaN operands are passed over.
+__device__ __forceinline__ float max3_abs(float m, float x, float y) {
+  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(x), "v"(y));
+  return m;
 }
 
 // Largest of the lanes' non-negative floats, as a wave-uniform bit pattern.  Row shifts and row
@@ -495,8 +524,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
       float fa_max = 0.0f, fb_max = 0.0f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        fa_max = fmaxf(fmaxf(fa_max, fmaxf(fabsf(av[u][0]), fabsf(av[u][1]))), fmaxf(fabsf(av[u][2]), fabsf(av[u][3])));
-        fb_max = fmaxf(fmaxf(fb_max, fmaxf(fabsf(bv[u][0]), fabsf(bv[u][1]))), fmaxf(fabsf(bv[u][2]), fabsf(bv[u][3])));
+        fa_max = max3_abs(max3_abs(fa_max, av[u][0], av[u][1]), av[u][2], av[u][3]);
+        fb_max = max3_abs(max3_abs(fb_max, bv[u][0], bv[u][1]), bv[u][2], bv[u][3]);
       }
       const uint32_t ma = wave_max_bits(fa_max), mb = wave_max_bits(fb_max);
       // A tile of zeros adds nothing, a step that an earlier pass over the chunk has taken is
@@ -519,17 +548,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
       xb2 = xb2 > 126 ? 126 : (xb2 < -126 ? -126 : xb2);
       const float fa = live ? __uint_as_float(static_cast<uint32_t>(127 + pa - ea) << 23) : 0.0f;
       const float fb = live ? __uint_as_float(static_cast<uint32_t>(127 + xb2) << 23) : 0.0f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v[8], w8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v[u] = av[u][j] * fa;
-          w8[u] = bv[u][j] * fb;
-        }
-        split_planes8(v, ah[j], am[j], al[j]);
-        split_planes8(w8, bh[j], bm[j], bl[j]);
-      }
+      split_tile(av, fa, ah, am, al);
+      split_tile(bv, fb, bh, bm, bl);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
