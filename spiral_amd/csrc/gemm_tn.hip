@@ -420,11 +420,14 @@ struct TnProblem {
 // the exponent S that every product of the wave's chunk carries (taken out when the partial
 // block is written): S = 14 - eA - eB, the middle of the range.  Every step then scales A by
 // 2^(pA - eA) and B by 2^(pB - eB) with pA + pB = eA + eB + S split evenly, which fits fp16 as
-// long as the step's operands are no more than 2^14 times larger than those S was set by; at a
-// step beyond that the wave adds what it has to its partial block under the old S, starts again
-// from zero and sets S by that step (rare, wave-uniform).  Steps far smaller than the one that set S lose relative, not
-// absolute accuracy (the residual plane keeps what plane 0 drops): the error stays relative to
-// the sum of absolute terms.  Domain: |a| |b| within 2^+-100.
+// long as the step's operands are no more than 2^14 times larger than those S was set by.  A
+// step beyond that is left out of this pass over the chunk (both operands multiplied by zero,
+// no branch around the matrix instructions); the wave writes what the pass summed to its
+// partial block under the pass's S and goes over the chunk again with S set by the largest
+// step it left, taking only the steps left (rare, wave-uniform: one pass unless a chunk's
+// operands grow 2^14-fold after its first rows).  Steps far smaller than the one that set S
+// lose relative, not absolute accuracy (the residual plane keeps what plane 0 drops): the
+// error stays relative to the sum of absolute terms.  Domain: |a| |b| within 2^+-100.
 template <bool F16>
 __global__ __launch_bounds__(kThreads, 1) void gemm_tn_partial_x3_wide_kernel(
     TnProblem first, TnProblem second, int n_problems, int64_t K, int M, int N, int64_t k_chunk,
