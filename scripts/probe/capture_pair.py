@@ -1,7 +1,6 @@
 """Times the paired weight-gradient launch on the operands a real train step hands it (captured
 from bench.py --mode train) beside random operands of the same shape, and prints how far the
 16-row blocks' magnitudes spread.  usage: capture_pair.py"""
-import math
 import os
 import sys
 
@@ -17,10 +16,9 @@ real = ops.gemm_tn_pair
 
 def spy(a0, b0, a1, b1, sums=False):
     if len(captured) < 2:
-        captured.append(tuple(t.clone() if t.is_contiguous() else t for t in (a0, b0, a1, b1)) + (sums,))
-        # keep views over a cloned base so that strides stay what the step used
-        a0c = a0.clone(memory_format=torch.preserve_format)
-        captured[-1] = (a0, b0.clone(), a1, b1.clone(), sums, a0.stride(), a1.stride())
+        # a0 and a1 are views of the step's packed gate gradients: kept as they are (strides
+        # included), the bench holds no reference that would overwrite them before the timing
+        captured.append((a0, b0.clone(), a1, b1.clone(), sums))
     return real(a0, b0, a1, b1, sums=sums)
 
 
@@ -46,9 +44,9 @@ def timed(fn, n=10):
     return s.elapsed_time(e) / n
 
 
-for idx, (a0, b0, a1, b1, sums, s0, s1) in enumerate(captured):
-    print(f"call {idx}: a0 {tuple(a0.shape)} stride {s0} b0 {tuple(b0.shape)} stride {b0.stride()} "
-          f"a1 {tuple(a1.shape)} stride {s1} b1 {tuple(b1.shape)} sums {sums}")
+for idx, (a0, b0, a1, b1, sums) in enumerate(captured):
+    print(f"call {idx}: a0 {tuple(a0.shape)} stride {a0.stride()} b0 {tuple(b0.shape)} stride {b0.stride()} "
+          f"a1 {tuple(a1.shape)} stride {a1.stride()} b1 {tuple(b1.shape)} sums {sums}")
     t_real = timed(lambda: real(a0, b0, a1, b1, sums=sums))
     for name, a, b in (("a0*b0", a0, b0), ("a1*b1", a1, b1)):
         k = a.shape[0] // 16 * 16
@@ -57,7 +55,6 @@ for idx, (a0, b0, a1, b1, sums, s0, s1) in enumerate(captured):
         t = ea + eb
         print(f"  {name}: exponent sums of 16-row blocks min {t.min().item():.0f} median {t.median().item():.0f} "
               f"max {t.max().item():.0f}; |a| max {a.abs().max().item():.3e} |b| max {b.abs().max().item():.3e}")
-    ra0 = torch.randn_like(a0) * 1e-3 if a0.is_contiguous() else None
     g = torch.randn(a0.shape[0], 512, device=a0.device) * 1e-3
     x = torch.randn_like(b0)
     h = torch.randn_like(b1)
