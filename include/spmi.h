@@ -467,6 +467,16 @@ int spmi_lstm_rows_fwd(const float* x /*device [M, I], row stride ldx*/, int64_t
                        const float* h_in /*device [M, H]*/, const float* c_in /*device [M, H]*/,
                        int64_t M, int64_t H, float* h_out /*device [M, H]*/,
                        float* c_out /*device [M, H]*/, int x_bounded, void* stream);
+/* The same step for a caller that will run a backward pass (torch.nn.LSTM under autograd in
+ * the reference's training loop, examples/torch/citation_prediction.py:96-101): besides h_out
+ * and c_out it writes saved [M, 6, H] = the planes i, f, g, o, the old cell state and
+ * tanh(c') of every row, the input of spmi_lstm_gate_bwd.  saved must overlap none of x, h_in,
+ * c_in, h_out, c_out.  (The tanh RNN needs no such variant: spmi_rnn_gate_bwd reads the
+ * output of spmi_rnn_rows_fwd.) */
+int spmi_lstm_rows_fwd_saved(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                             const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
+                             int64_t M, int64_t H, float* h_out, float* c_out,
+                             float* saved /*device [M, 6, H]*/, int x_bounded, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dense projection of a tall matrix: out = act(x W^T + bias), x [M, K] fp32, W [N, K].

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "spmi_lstm_rows_supported": (c_int, [c_i64, c_i64]),
     "spmi_lstm_rows_fwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
                                    c_vp, c_vp, c_int, c_vp]),
+    "spmi_lstm_rows_fwd_saved": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
+                                         c_vp, c_vp, c_vp, c_int, c_vp]),
     "spmi_gat_edge_softmax": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp,
                                       c_vp, c_i32, c_i32, c_vp]),
     "spmi_gat_edge_softmax_bwd": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp,

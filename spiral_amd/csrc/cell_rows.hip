@@ -390,6 +390,7 @@ struct LstmRowsArgs {
   const float* c_in;
   float* h_out;
   float* c_out;
+  float* saved;  // nullable: [M][6][H] = i, f, g, o, old cell state, tanh(new cell state)
   int64_t M;
   int x_bounded;
 };
@@ -424,12 +425,15 @@ constexpr int kLstmWaves = 4;
 
 // RNN: the four column tiles are the four 32-unit blocks of ONE gate (the tanh RNN, H = 128):
 // the workgroup holds every column, rows are read once.
-template <int KT, bool RNN>
+// SAVE: the gate values a backward pass needs go to p.saved, in the layout lstm_fwd_kernel
+// (gates.hip) writes, which is the one spmi_lstm_gate_bwd reads.
+template <int KT, bool RNN, bool SAVE = false>
 __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsArgs p) {
   constexpr int H = KT * 16;
   constexpr int GH = RNN ? H : 4 * H;
   constexpr int NS = RNN ? 1 : H / 32;
   static_assert(!RNN || H == 128, "four column tiles");
+  static_assert(!(RNN && SAVE), "the tanh RNN's backward needs its output only");
   constexpr int B16 = 2 * KT * kStep4 / 16;
   static_assert(KT % 2 == 0, "K-steps come in pairs");
   static_assert(32 % NS == 0, "slices of one row range must fit the workgroups of one XCD");
@@ -599,11 +603,21 @@ __global__ __launch_bounds__(kLstmWaves * 64, 1) void lstm_rows_kernel(LstmRowsA
         const float gg = tanhf_(__builtin_fmaf(sml[2][e], 0x1p-6f, acc[2][e]) + bias[2]);
         const float go = sigmoidf_(__builtin_fmaf(sml[3][e], 0x1p-6f, acc[3][e]) + bias[3]);
         const float c = gf * cy[e] + gi * gg;
-        const float h = go * tanhf_(c);
+        const float tc = tanhf_(c);
+        const float h = go * tc;
         const int ur = (e & 3) + 8 * (e >> 2);
         if (whole || row0 + ur + 4 * lh < p.M) {
           cb[ur * H + voff] = c;
           hb[ur * H + voff] = h;
+          if constexpr (SAVE) {
+            float* sv = p.saved + (row0 + ur + 4 * lh) * (6 * H) + j;
+            sv[0] = gi;
+            sv[H] = gf;
+            sv[2 * H] = gg;
+            sv[3 * H] = go;
+            sv[4 * H] = cy[e];
+            sv[5 * H] = tc;
+          }
         }
       }
     }
@@ -615,8 +629,9 @@ template <int KT>
 int launch_lstm(const LstmRowsArgs& a, hipStream_t st) {
   constexpr size_t lds = static_cast<size_t>(2 * KT) * kStep4;
   static_assert(lds <= 160 * 1024, "slice image does not fit LDS");
-  auto kern = lstm_rows_kernel<KT, false>;
-  SPMI_RAISE_LDS_LIMIT(kern, lds);
+  auto kern = a.saved ? lstm_rows_kernel<KT, false, true> : lstm_rows_kernel<KT, false>;
+  SPMI_RAISE_LDS_LIMIT((lstm_rows_kernel<KT, false>), lds);  // each use keeps its own record
+  SPMI_RAISE_LDS_LIMIT((lstm_rows_kernel<KT, false, true>), lds);
   constexpr int NS = KT / 2;
   const int64_t n_tiles = (a.M + 31) / 32;
   int64_t sets = (n_tiles + 8 * kLstmWaves - 1) / (8 * kLstmWaves);  // a set: 8 row groups of kLstmWaves tiles
@@ -771,9 +786,10 @@ int spmi_rnn_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih,
 
 int spmi_lstm_rows_supported(int64_t I, int64_t H) { return I == 128 && H == 128; }
 
-int spmi_lstm_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
-                       const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
-                       int64_t M, int64_t H, float* h_out, float* c_out, int x_bounded, void* stream) {
+static int lstm_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                         const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
+                         int64_t M, int64_t H, float* h_out, float* c_out, float* saved, int x_bounded,
+                         void* stream) {
   SPMI_REQUIRE(spmi_lstm_rows_supported(I, H), SPMI_ERR_UNSUPPORTED,
                "spmi_lstm_rows_fwd: needs I = H = 128 (I=%lld H=%lld)", (long long)I, (long long)H);
   SPMI_REQUIRE(M >= 0 && M < (int64_t{1} << 31), SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: bad M=%lld",
@@ -802,13 +818,36 @@ int spmi_lstm_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih
     SPMI_REQUIRE(apart(co, bytes, hi, bytes) && apart(co, bytes, x0, xbytes) && apart(co, bytes, ho, bytes) &&
                      (co == ci || apart(co, bytes, ci, bytes)),
                  SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd: c_out overlaps an input (other than being c_in)");
+    if (saved) {
+      const uintptr_t s0 = reinterpret_cast<uintptr_t>(saved), sbytes = 6 * bytes;
+      SPMI_REQUIRE((s0 & 15u) == 0, SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd_saved: saved must be 16-byte aligned");
+      SPMI_REQUIRE(apart(s0, sbytes, hi, bytes) && apart(s0, sbytes, ci, bytes) && apart(s0, sbytes, ho, bytes) &&
+                       apart(s0, sbytes, co, bytes) && apart(s0, sbytes, x0, xbytes),
+                   SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd_saved: saved overlaps x or a state matrix");
+    }
   }
   LstmRowsArgs a{};
   a.x = x; a.ldx = ldx;
   a.ws_ih = static_cast<const uint4*>(ws_ih); a.ws_hh = static_cast<const uint4*>(ws_hh);
   a.b_ih = b_ih; a.b_hh = b_hh; a.h_in = h_in; a.c_in = c_in; a.h_out = h_out; a.c_out = c_out;
-  a.M = M; a.x_bounded = x_bounded;
+  a.saved = saved; a.M = M; a.x_bounded = x_bounded;
   return launch_lstm<8>(a, spmi::as_stream(stream));
+}
+
+int spmi_lstm_rows_fwd(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                       const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
+                       int64_t M, int64_t H, float* h_out, float* c_out, int x_bounded, void* stream) {
+  return lstm_rows_fwd(x, ldx, I, ws_ih, ws_hh, b_ih, b_hh, h_in, c_in, M, H, h_out, c_out, nullptr, x_bounded,
+                       stream);
+}
+
+int spmi_lstm_rows_fwd_saved(const float* x, int64_t ldx, int64_t I, const void* ws_ih, const void* ws_hh,
+                             const float* b_ih, const float* b_hh, const float* h_in, const float* c_in,
+                             int64_t M, int64_t H, float* h_out, float* c_out, float* saved, int x_bounded,
+                             void* stream) {
+  SPMI_REQUIRE(saved || M == 0, SPMI_ERR_INVALID_ARG, "spmi_lstm_rows_fwd_saved: saved is null");
+  return lstm_rows_fwd(x, ldx, I, ws_ih, ws_hh, b_ih, b_hh, h_in, c_in, M, H, h_out, c_out, saved, x_bounded,
+                       stream);
 }
 
 }  // extern "C"

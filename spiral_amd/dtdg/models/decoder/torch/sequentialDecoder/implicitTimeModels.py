@@ -347,12 +347,28 @@ class RNN(SequentialDecoder):
 
     def _step(self, x, ids):
         mem = self.memory_h
+        every_node = (ids is None and x.shape[0] == mem.rows()
+                      and self._layer_params(0)[0].shape[1] == x.shape[1])
+        params = [self._layer_params(k) for k in range(self.n_layers)]
+        tracked = torch.is_grad_enabled() and (x.requires_grad or any(
+            t is not None and t.requires_grad for ps in params for t in ps))
+        if every_node and tracked and all(ops.rnn_rows_tracked_ok(x if k == 0 else mem.layer(k), params[k][1])
+                                          for k in range(self.n_layers)):
+            # every node, under autograd: the same kernel, its output kept by the graph and
+            # adopted by the memory as it is (see GRU._step)
+            new = []
+            for k in range(self.n_layers):
+                h = ops.rnn_rows_tracked(x, *params[k], mem.layer(k), x_bounded=k > 0)
+                new.append(h)
+                x = self._between_layers(h, k)
+            if self.training_mode:
+                mem.set_layers(new)
+            return x
         # every node, nothing tracked: the kernel that keeps the weights in LDS (see GRU._step)
-        whole = (ids is None and x.shape[0] == mem.memory.shape[1]
+        whole = (every_node and not tracked
                  and all(ops.rnn_rows_ok(x if k == 0 else mem.memory[k], self._layer_params(k)[1],
                                          *self._layer_params(k)[::2], self._layer_params(k)[3])
-                         for k in range(self.n_layers))
-                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+                         for k in range(self.n_layers)))
         if whole:
             new = mem.spare() if self.training_mode else None
             for k in range(self.n_layers):
@@ -387,14 +403,34 @@ class LSTM(SequentialDecoder):
 
     def _step(self, x, ids):
         mh, mc = self.memory_h, self.memory_c
+        every_node = (ids is None and x.shape[0] == mh.rows()
+                      and self._layer_params(0)[0].shape[1] == x.shape[1])
+        params = [self._layer_params(k) for k in range(self.n_layers)]
+        tracked = torch.is_grad_enabled() and (x.requires_grad or any(
+            t is not None and t.requires_grad for ps in params for t in ps))
+        if every_node and tracked and all(ops.lstm_rows_tracked_ok(x if k == 0 else mh.layer(k), params[k][1])
+                                          for k in range(self.n_layers)):
+            # every node, under autograd: the same kernel with the gate values kept; both
+            # memories adopt the layers' new states as they are (see GRU._step)
+            new_h, new_c = [], []
+            for k in range(self.n_layers):
+                # h' = sigmoid(o) * tanh(c'): bounded by 1 whatever the state holds
+                h, c = ops.lstm_rows_tracked(x, *params[k], mh.layer(k), mc.layer(k), x_bounded=k > 0)
+                new_h.append(h)
+                new_c.append(c)
+                x = self._between_layers(h, k)
+            if self.training_mode:
+                mh.set_layers(new_h)
+                mc.set_layers(new_c)
+                mc._bounded = None  # c' = f c + i g may grow by one a step
+            return x
         # Every node, nothing tracked: the kernel that keeps the gate weights in LDS (see
         # GRU._step).  The new hidden state goes to the memory's second table; the cell state
         # is updated in place when the step writes back, into a scratch table otherwise.
-        whole = (ids is None and x.shape[0] == mh.memory.shape[1]
+        whole = (every_node and not tracked
                  and all(ops.lstm_rows_ok(x if k == 0 else mh.memory[k], self._layer_params(k)[1],
                                           *self._layer_params(k)[::2], self._layer_params(k)[3])
-                         for k in range(self.n_layers))
-                 and self._layer_params(0)[0].shape[1] == x.shape[1])
+                         for k in range(self.n_layers)))
         if whole:
             new_h = mh.spare() if self.training_mode else None
             for k in range(self.n_layers):

@@ -1267,6 +1267,140 @@ def gru_rows_tracked(x, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, x_bounded: b
                           bool(x_bounded))
 
 
+def _whole_table_tracked_ok(supported: str, x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+    """The conditions of `_whole_table_ok` without the one that nothing be tracked."""
+    return (USE_FUSED_CELLS and USE_GRU_ROWS and CELL_GEMM == "f16x3" and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(getattr(nv.lib(), supported)(x.shape[1], w_hh.shape[1])))
+
+
+def _cell_grads_from_gates(ctx, g_g, xd, h_old, w_ih):
+    """(g_x, g_w_ih, g_w_hh, g_b_ih, g_b_hh) of an LSTM or tanh-RNN layer from the gradient of
+    its gate pre-activations g_g [M, G] (the same matrix for the input and the state side), the
+    layer's input rows and its old state.  Both weight gradients and the bias gradient come
+    from one launch where the shapes allow it."""
+    g_x = None
+    if ctx.needs_input_grad[0]:
+        wt = w_ih.detach()                                      # [G, I]
+        g_x = gemm_rows(g_g, wt.t()) if _gemm_rows_ok(g_g, wt.shape[0], wt.shape[1]) else g_g @ wt
+    need_b = ctx.has_bias and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+    if (GRU_PAIRED_WEIGHT_GRADS and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+            and gemm_tn_pair_ok(g_g, xd, g_g, h_old)):
+        g_wih, g_whh, g_b, _ = gemm_tn_pair(g_g, xd, g_g, h_old, sums=True)
+        if not need_b:
+            g_b = None
+    else:
+        g_wih, g_b = _weight_and_bias_grad(g_g, xd, ctx.needs_input_grad[1], need_b, dy_first=True)
+        g_whh = gemm_tn(g_g, h_old) if ctx.needs_input_grad[2] else None
+    return g_x, g_wih, g_whh, g_b, g_b
+
+
+def lstm_rows_tracked_ok(x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+    """The whole-table LSTM kernel takes this layer as a tracked step (`lstm_rows_tracked`)."""
+    return _whole_table_tracked_ok("spmi_lstm_rows_supported", x, w_hh)
+
+
+class LstmRowsTracked(torch.autograd.Function):
+    """One LSTM layer step over every row of the state matrices `h_in`, `c_in` [M, H] on the
+    kernel that keeps the gate weights in LDS, with the gate values kept for the backward pass.
+    The new states are the returned tensors (storage of their own); h_in and c_in are read,
+    never written.  The cell state carries no gradient to the caller (the node memory is a
+    buffer between steps, as in LstmCell)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_in, c_in, x_bounded):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        _check_cell_args(xd, h_in, None)
+        nv.require_cuda(c_in)
+        for t in (h_in, c_in):
+            if t.shape != (m, hd) or not t.is_contiguous() or t.dtype != torch.float32 or t.device != x.device:
+                raise nv.SpmiError("lstm_rows_tracked: h_in and c_in must be the contiguous float32 [M, H] "
+                                   "states of the rows of x")
+        need_grad = _needs_grad(ctx, 5)
+        saved = torch.empty(m, 6 * hd, dtype=torch.float32, device=x.device) if need_grad else None
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        c_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        ws_ih = weight_planes(w_ih, "f16x3", False, F16X3_CELL_LIMIT)
+        ws_hh = weight_planes(w_hh, "f16x3", False, F16X3_CELL_LIMIT)
+        with torch.cuda.device(x.device):
+            if saved is None:
+                nv.check(nv.lib().spmi_lstm_rows_fwd(
+                    nv.ptr(xd), xd.stride(0), xd.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+                    nv.ptr(b_hh), nv.ptr(h_in), nv.ptr(c_in), m, hd, nv.ptr(h_out), nv.ptr(c_out),
+                    int(x_bounded), nv.stream()), "spmi_lstm_rows_fwd")
+            else:
+                nv.check(nv.lib().spmi_lstm_rows_fwd_saved(
+                    nv.ptr(xd), xd.stride(0), xd.shape[1], nv.ptr(ws_ih), nv.ptr(ws_hh), nv.ptr(b_ih),
+                    nv.ptr(b_hh), nv.ptr(h_in), nv.ptr(c_in), m, hd, nv.ptr(h_out), nv.ptr(c_out),
+                    nv.ptr(saved), int(x_bounded), nv.stream()), "spmi_lstm_rows_fwd_saved")
+        ctx.save_for_backward(xd, w_ih, w_hh, saved, h_in)
+        ctx.has_bias = b_ih is not None
+        ctx.mark_non_differentiable(c_out)
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, g_h, _g_c):
+        xd, w_ih, w_hh, saved, h_in = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g_g = torch.empty(m, 4 * hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_lstm_gate_bwd(nv.ptr(g_h), None, nv.ptr(saved), m, hd,
+                                                 nv.ptr(g_g), None, nv.stream()),
+                     "spmi_lstm_gate_bwd")
+        return _cell_grads_from_gates(ctx, g_g, xd, h_in, w_ih) + (None, None, None)
+
+
+def lstm_rows_tracked(x, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, c_in: torch.Tensor,
+                      x_bounded: bool = False):
+    """One LSTM layer step for every row under autograd: the state matrices `h_in`, `c_in`
+    [M, H] are read (h_in is kept for the backward pass: it must not be written before that
+    pass has run), the new states (h', c') come back as tensors of their own."""
+    return _apply_tracked(LstmRowsTracked, (x, w_ih, w_hh, b_ih, b_hh), x, w_ih, w_hh, b_ih, b_hh, h_in,
+                          c_in, bool(x_bounded))
+
+
+def rnn_rows_tracked_ok(x: torch.Tensor, w_hh: torch.Tensor) -> bool:
+    """The whole-table tanh-RNN kernel takes this layer as a tracked step (`rnn_rows_tracked`)."""
+    return _whole_table_tracked_ok("spmi_rnn_rows_supported", x, w_hh)
+
+
+class RnnRowsTracked(torch.autograd.Function):
+    """One tanh-RNN layer step over every row of the state matrix `h_in` [M, H] on the kernel
+    that keeps the weights in LDS.  The backward pass needs the output and the old state only,
+    so the forward is the inference kernel as it is."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_in, x_bounded):
+        m, hd = x.shape[0], w_hh.shape[1]
+        xd = x.detach()
+        h_out = torch.empty(m, hd, dtype=torch.float32, device=x.device)
+        rnn_rows(xd, w_ih, w_hh, b_ih, b_hh, h_in, h_out, x_bounded=x_bounded)
+        ctx.save_for_backward(xd, w_ih, w_hh, h_out, h_in)
+        ctx.has_bias = b_ih is not None
+        return h_out
+
+    @staticmethod
+    def backward(ctx, g_h):
+        xd, w_ih, w_hh, h_out, h_in = ctx.saved_tensors
+        m, hd = g_h.shape
+        g_h = g_h.contiguous()
+        g_g = torch.empty(m, hd, dtype=torch.float32, device=g_h.device)
+        with torch.cuda.device(g_h.device):
+            nv.check(nv.lib().spmi_rnn_gate_bwd(nv.ptr(g_h), nv.ptr(h_out), m, hd, nv.ptr(g_g),
+                                                nv.stream()), "spmi_rnn_gate_bwd")
+        return _cell_grads_from_gates(ctx, g_g, xd, h_in, w_ih) + (None, None)
+
+
+def rnn_rows_tracked(x, w_ih, w_hh, b_ih, b_hh, h_in: torch.Tensor, x_bounded: bool = False) -> torch.Tensor:
+    """One tanh-RNN layer step for every row under autograd: the state matrix `h_in` [M, H] is
+    read (and kept for the backward pass), the new state comes back as a tensor of its own."""
+    return _apply_tracked(RnnRowsTracked, (x, w_ih, w_hh, b_ih, b_hh), x, w_ih, w_hh, b_ih, b_hh, h_in,
+                          bool(x_bounded))
+
+
 class LstmCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h_mem, c_mem, ids, mem_write):

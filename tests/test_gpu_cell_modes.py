@@ -312,3 +312,120 @@ def test_tracked_whole_table_steps_through_the_decoder(dev):
     for k in grads_b:
         assert float((grads_a[k] - grads_b[k]).abs().max()) / scale < 1e-5, k
 
+
+
+@pytest.mark.parametrize("m", [6000, 33, 4096 + 17, 20_000])
+def test_tracked_whole_table_lstm_step(dev, m):
+    """The whole-table LSTM kernel as a tracked step (six planes kept per state element, the old
+    hidden state read from the matrix it came from) against torch.nn.LSTMCell in float64: both new
+    states and the gradients of x, both weights and both biases within 1e-5 of each tensor's
+    largest entry; the state matrices it read are left as they were.  At 20000 rows both weight
+    gradients and the bias gradient come from one launch (spmi_gemm_tn_pair_sums)."""
+    i = h = 128
+    w_ih, w_hh, b_ih, b_hh = _params(4, i, h, dev, 22)
+    gen = torch.Generator().manual_seed(m + 1)
+    x0 = torch.randn(m, i, generator=gen).to(dev)
+    h0 = (torch.randn(m, h, generator=gen) * 0.5).to(dev)
+    c0 = torch.randn(m, h, generator=gen).to(dev)
+    wgt = torch.randn(m, h, generator=gen).to(dev) * 1e-3
+    leaves = [t.clone().requires_grad_() for t in (x0, w_ih, w_hh, b_ih, b_hh)]
+    h_in, c_in = h0.clone(), c0.clone()
+    assert ops.lstm_rows_tracked_ok(leaves[0], leaves[2])
+    out, c_new = ops.lstm_rows_tracked(leaves[0], *leaves[1:], h_in, c_in)
+    assert out.data_ptr() != h_in.data_ptr() and c_new.data_ptr() != c_in.data_ptr()
+    assert torch.equal(h_in, h0) and torch.equal(c_in, c0) and not c_new.requires_grad
+    (out * wgt).sum().backward()
+
+    cell = torch.nn.LSTMCell(i, h).double()
+    with torch.no_grad():
+        for p, t in zip((cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh), (w_ih, w_hh, b_ih, b_hh)):
+            p.copy_(t.double().cpu())
+    xr = x0.double().cpu().requires_grad_()
+    ref_h, ref_c = cell(xr, (h0.double().cpu(), c0.double().cpu()))
+    (ref_h * wgt.double().cpu()).sum().backward()
+    assert float((out.detach().double().cpu() - ref_h.detach()).abs().max()) < 1e-5
+    assert float((c_new.double().cpu() - ref_c.detach()).abs().max()) < 1e-5 * float(ref_c.detach().abs().max())
+    want = [xr.grad, cell.weight_ih.grad, cell.weight_hh.grad, cell.bias_ih.grad, cell.bias_hh.grad]
+    for got, r, name in zip([t.grad for t in leaves], want, ("x", "w_ih", "w_hh", "b_ih", "b_hh")):
+        e = float((got.double().cpu() - r).abs().max()) / float(r.abs().max())
+        assert e < 1e-5, (name, e)
+    # the same numbers as the inference kernel (one loop nest, one epilogue)
+    with torch.no_grad():
+        ph, pc = ops.lstm_rows(x0, w_ih, w_hh, b_ih, b_hh, h0, c0, torch.empty_like(h0), torch.empty_like(c0))
+    assert torch.equal(ph, out.detach()) and torch.equal(pc, c_new)
+
+
+@pytest.mark.parametrize("m", [6000, 33, 4096 + 17, 20_000])
+def test_tracked_whole_table_rnn_step(dev, m):
+    """The whole-table tanh-RNN kernel as a tracked step against torch.nn.RNNCell in float64: new
+    state and the gradients of x, both weights and both biases within 1e-5 of each tensor's
+    largest entry; the state matrix it read is left as it was."""
+    i = h = 128
+    w_ih, w_hh, b_ih, b_hh = _params(1, i, h, dev, 23)
+    gen = torch.Generator().manual_seed(m + 2)
+    x0 = torch.randn(m, i, generator=gen).to(dev)
+    h0 = (torch.randn(m, h, generator=gen) * 0.5).to(dev)
+    wgt = torch.randn(m, h, generator=gen).to(dev) * 1e-3
+    leaves = [t.clone().requires_grad_() for t in (x0, w_ih, w_hh, b_ih, b_hh)]
+    h_in = h0.clone()
+    assert ops.rnn_rows_tracked_ok(leaves[0], leaves[2])
+    out = ops.rnn_rows_tracked(leaves[0], *leaves[1:], h_in)
+    assert out.data_ptr() != h_in.data_ptr() and torch.equal(h_in, h0)
+    (out * wgt).sum().backward()
+
+    cell = torch.nn.RNNCell(i, h).double()
+    with torch.no_grad():
+        for p, t in zip((cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh), (w_ih, w_hh, b_ih, b_hh)):
+            p.copy_(t.double().cpu())
+    xr = x0.double().cpu().requires_grad_()
+    ref = cell(xr, h0.double().cpu())
+    (ref * wgt.double().cpu()).sum().backward()
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) < 1e-5
+    want = [xr.grad, cell.weight_ih.grad, cell.weight_hh.grad, cell.bias_ih.grad, cell.bias_hh.grad]
+    for got, r, name in zip([t.grad for t in leaves], want, ("x", "w_ih", "w_hh", "b_ih", "b_hh")):
+        e = float((got.double().cpu() - r).abs().max()) / float(r.abs().max())
+        assert e < 1e-5, (name, e)
+
+
+@pytest.mark.parametrize("kind", ["LSTM", "RNN"])
+def test_tracked_whole_table_lstm_and_rnn_through_their_decoders(dev, kind):
+    """Two tracked steps of the LSTM / RNN decoder over every node: the memories adopt each
+    step's outputs without a copy, a loss summed over both steps goes backward through both
+    graphs, and the tables read afterwards equal the second step's states.  Against the same
+    decoder on the row-tile path."""
+    from spiral_amd.dtdg.models.decoder.torch.sequentialDecoder import implicitTimeModels as itm
+    from spiral_amd.dtdg.models.decoder.torch.simpleDecoder import MLP
+
+    n, hd = 5000, 128
+
+    def run(rows_kernel):
+        old, ops.USE_GRU_ROWS = ops.USE_GRU_ROWS, rows_kernel
+        try:
+            torch.manual_seed(7)
+            dec = getattr(itm, kind)(hd, hd, n, 2, MLP(hd, [16], dropout=0.0)).to(dev)
+            dec.train()
+            torch.manual_seed(8)
+            for name in dec._memories():
+                getattr(dec, name).reset_state()
+                setattr(dec, name, getattr(dec, name).to(dev))
+            xs = [torch.randn(n, hd, device=dev, generator=torch.Generator(dev).manual_seed(60 + t)) for t in range(2)]
+            loss = 0
+            for x in xs:
+                out = dec((x, list(range(n))))
+                loss = loss + out.pow(2).mean()
+            adopted = all(getattr(dec, name)._layers is not None for name in dec._memories())
+            loss.backward()
+            grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
+            return float(loss.detach()), grads, [getattr(dec, name).memory.clone() for name in dec._memories()], adopted
+        finally:
+            ops.USE_GRU_ROWS = old
+
+    loss_a, grads_a, mems_a, adopted_a = run(True)
+    loss_b, grads_b, mems_b, adopted_b = run(False)
+    assert adopted_a and not adopted_b
+    assert abs(loss_a - loss_b) <= 1e-5 * abs(loss_b)
+    for ma, mb in zip(mems_a, mems_b):
+        assert float((ma - mb).abs().max()) < 1e-5 * max(1.0, float(mb.abs().max()))
+    scale = max(float(g.abs().max()) for g in grads_b.values())
+    for k in grads_b:
+        assert float((grads_a[k] - grads_b[k]).abs().max()) / scale < 1e-5, k
